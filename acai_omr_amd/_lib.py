@@ -1,0 +1,103 @@
+"""ctypes binding of the C-ABI shared library (include/acai_omr_hip.h).
+
+The product path has NO CPU fallback: if `libacai_omr_hip.so` is missing or a symbol is absent, importing
+the ops raises, loudly.  `build()` compiles the library in-tree for gfx950 with hipcc (cross-compiles
+without a GPU); the built .so is git-ignored but travels to the GPU box with the source tree.
+"""
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(CSRC, "libacai_omr_hip.so")
+SOURCES = ["gemm.hip", "elementwise.hip", "attn_varlen.hip", "decode.hip"]
+
+ACAI_F32, ACAI_BF16 = 0, 1
+GEMM_GELU, GEMM_ROUND_BF16 = 1, 2
+
+
+class AcaiDecLayer(Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "self_in_w", "self_in_b", "self_out_w", "self_out_b", "cross_q_w", "cross_q_b", "cross_out_w", "cross_out_b",
+        "lin1_w", "lin1_b", "lin2_w", "lin2_b", "n1_w", "n1_b", "n2_w", "n2_b", "n3_w", "n3_b",
+        "k_self", "v_self", "k_cross", "v_cross")]
+
+
+class AcaiDecoder(Structure):
+    _fields_ = [(n, c_int32) for n in (
+        "B", "E", "H", "dh", "dhp", "F", "V", "L", "Tmax", "dtype", "flags", "max_len",
+        "self_chunk", "cross_chunk", "self_nsplit", "cross_nsplit", "bos", "pad", "eos", "reserved")] + [
+        ("layers", POINTER(AcaiDecLayer))] + [(n, c_void_p) for n in (
+            "emb", "pos", "fn_w", "fn_b", "unembed_w", "unembed_b", "cross_off", "cross_len", "seqs", "logprobs",
+            "step", "finished", "x", "xn", "qkv", "attn", "proj", "hid", "logits", "partial")]
+
+
+_SIGNATURES = {
+    "acai_version": (c_int, []),
+    "acai_last_error": (c_char_p, []),
+    "acai_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "acai_gemm_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                             c_int, c_int, c_int, c_void_p]),
+    "acai_cross_kv_prefill": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "acai_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "acai_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "acai_attn_varlen_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                     c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "acai_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "acai_skinny_gemm": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                 c_int, c_int, c_void_p]),
+    "acai_decode_attn": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                 c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "acai_decode_step": (c_int, [POINTER(AcaiDecoder), c_void_p]),
+    "acai_decode_logits": (c_int, [POINTER(AcaiDecoder), c_void_p, c_int, c_void_p]),
+    "acai_decode_hidden": (c_int, [POINTER(AcaiDecoder), c_void_p, c_void_p]),
+    "acai_graph_begin": (c_int, [c_void_p]),
+    "acai_graph_end": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "acai_graph_launch": (c_int, [c_void_p, c_void_p]),
+    "acai_graph_destroy": (c_int, [c_void_p]),
+}
+
+_lib = None
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -shared over csrc/*.hip -> csrc/libacai_omr_hip.so (in-tree)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(CSRC), "..", "include", "acai_omr_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = "hipcc" if subprocess.run(["which", "hipcc"], capture_output=True).returncode == 0 else "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def lib():
+    """Load (once) and type the C-ABI library.  Raises if it is missing: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"acai_omr_amd: HIP extension {LIB_PATH} is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                           "there is no CPU fallback for the product path")
+    L = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if L.acai_version() != 1:
+        raise RuntimeError("acai_omr_amd: ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {lib().acai_last_error().decode()}")
+
+
+def exported_symbols():
+    return list(_SIGNATURES)

@@ -1,0 +1,279 @@
+// Flash-style varlen attention forward on packed ragged streams (no padding, no mask tensor):
+// replaces nn.MultiheadAttention's SDPA inside nn.TransformerEncoderLayer / nn.TransformerDecoderLayer
+// (reference: acai_omr/models/models.py:30-34,186-190,351-360,422-426; masks M:70-73, M:468).
+//
+// gfx950 design.  Workgroup = 4 waves = 128 queries of one (sequence, head); each wave owns 32 queries
+// and streams 64-key K/V tiles that the workgroup stages in LDS (K row-major [key][d], V transposed
+// [d][key]).  Both products are "swapped" so that a query lives on a LANE and keys/d live in REGISTERS:
+//   S^T[key][q] = K . Q^T   A = K rows (ds_read_b128), B = Q fragments held in registers for the whole kernel
+//   O^T[d][q]   = V^T . P^T A = V^T rows (LDS),          B = P, taken straight from the S^T accumulators
+// With the 32x32 MFMA C/D layout (col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)) the softmax row
+// statistics are per-lane scalars (31 v_max + one cross-half exchange), the rescale of O is a per-lane
+// multiply, and P never touches LDS: the accumulator registers 8s..8s+7, packed to bf16, ARE the B
+// fragment of k-step s when the A fragment takes keys 16s + 8(j>>2) + 4h + (j&3) (fp32: one register per
+// K=2 MFMA with A key (i&3)+8(i>>2)+4h).  bf16 -> v_mfma_f32_32x32x16_bf16, fp32 -> v_mfma_f32_32x32x2_f32.
+// Online softmax in fp32 with exp2 and a finite -1e30 floor; global loads of tile t+1 are issued before
+// the MFMAs of tile t (issue-early / write-late), one LDS stage.
+#include "common.h"
+
+namespace {
+
+constexpr int KT = 64;   // keys per tile
+constexpr int QB = 128;  // queries per workgroup
+
+struct AttnArgs {
+    const void *q, *k, *v;
+    void *out;
+    const int32_t *cu_q, *cu_k;
+    int ldq, ldk, ldv, ldo, H, dh, causal;
+    float scale_log2e;
+};
+
+template <typename T, int DHP, bool FAST>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    constexpr int ES = sizeof(T);
+    constexpr int EPC = 16 / ES;                 // elements per 16-byte chunk
+    constexpr int KPITCH = DHP * ES + 16;        // bytes per K row in LDS
+    constexpr int VPITCH = KT * ES + 16;         // bytes per V^T row in LDS
+    constexpr int NS = DHP * ES / 32;            // 16-byte fragments per lane along d (per lane-half)
+    constexpr int NDB = DHP / 32;                // 32-wide d blocks of the output
+    constexpr int CPR = DHP / EPC;               // 16-byte chunks per K/V row
+    constexpr int NCH = KT * CPR / 256;          // chunks per thread per operand
+    __shared__ __attribute__((aligned(16))) unsigned char lds[KT * KPITCH + DHP * VPITCH];
+    unsigned char *ldsK = lds, *ldsV = lds + KT * KPITCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q_start = a.cu_q[b], lq = a.cu_q[b + 1] - q_start;
+    const int k_start = a.cu_k[b], lk = a.cu_k[b + 1] - k_start;
+    const int q0 = blockIdx.x * QB;
+    if (q0 >= lq) return;  // whole workgroup exits together: no barrier has been reached yet
+
+    const T *Q = reinterpret_cast<const T *>(a.q) + (size_t)q_start * a.ldq + h * a.dh;
+    const T *K = reinterpret_cast<const T *>(a.k) + (size_t)k_start * a.ldk + h * a.dh;
+    const T *V = reinterpret_cast<const T *>(a.v) + (size_t)k_start * a.ldv + h * a.dh;
+    T *O = reinterpret_cast<T *>(a.out) + (size_t)q_start * a.ldo + h * a.dh;
+    const int dh = a.dh;
+
+    auto load16 = [&](const T *base, int ld, int row, int rows, int d0) -> uint4 {
+        uint4 r = make_uint4(0, 0, 0, 0);
+        if (row >= rows) return r;
+        if constexpr (FAST) {
+            if (d0 < dh) r = *reinterpret_cast<const uint4 *>(base + (size_t)row * ld + d0);
+        } else {
+            union { uint4 v; T e[EPC]; } u;
+            u.v = r;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e)
+                if (d0 + e < dh) u.e[e] = base[(size_t)row * ld + d0 + e];
+            r = u.v;
+        }
+        return r;
+    };
+
+    // ---- Q fragments: lane (q = lr, half lh) keeps d = (32 s + 16 lh)/ES .. for s = 0..NS-1 -----------------
+    const int my_q = q0 + wave * 32 + lr;
+    uint4 qf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qf[s] = load16(Q, a.ldq, my_q, lq, (s * 32 + lh * 16) / ES);
+
+    f32x16 oacc[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+    float m_run = -1.0e30f, l_run = 0.f;  // running max (scaled, log2 domain) and this lane-half's partial sum
+
+    int nkt = (lk + KT - 1) / KT;
+    if (a.causal) {
+        const int last_q = min(q0 + QB, lq) - 1;
+        nkt = min(nkt, last_q / KT + 1);
+    }
+
+    uint4 rk[NCH], rv[NCH];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 256 * i, row = c / CPR, d0 = (c % CPR) * EPC;
+            rk[i] = load16(K, a.ldk, kt * KT + row, lk, d0);
+            rv[i] = load16(V, a.ldv, kt * KT + row, lk, d0);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 256 * i, row = c / CPR, cc = c % CPR;
+            *reinterpret_cast<uint4 *>(ldsK + row * KPITCH + cc * 16) = rk[i];
+            union { uint4 v; T e[EPC]; } u;
+            u.v = rv[i];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e)  // transpose: V^T[d][key]
+                *reinterpret_cast<T *>(ldsV + (cc * EPC + e) * VPITCH + row * ES) = u.e[e];
+        }
+    };
+
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) load_tile(kt + 1);
+
+        // ---- S^T = K . Q^T : two 32-key blocks ---------------------------------------------------------
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const uint4 kf = *reinterpret_cast<const uint4 *>(ldsK + (kb * 32 + lr) * KPITCH + s * 32 + lh * 16);
+                if constexpr (ES == 2) {
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
+                                                                       __builtin_bit_cast(bf16x8, qf[s]), sacc[kb], 0, 0, 0);
+                } else {
+                    const f32x4 k4 = __builtin_bit_cast(f32x4, kf), q4 = __builtin_bit_cast(f32x4, qf[s]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(k4[e], q4[e], sacc[kb], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- mask + online softmax (per-lane query) ----------------------------------------------------
+        const int key_lim = a.causal ? min(lk, my_q + 1) : lk;  // keys < key_lim are attended
+        float tmax = -1.0e30f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kt * KT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const float sv = key < key_lim ? sacc[kb][e] * a.scale_log2e : -1.0e30f;
+                sacc[kb][e] = sv;
+                tmax = fmaxf(tmax, sv);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                // masked entries: exp2(-1e30 - m) = 0 once m is finite; a fully masked row keeps m = -1e30 and
+                // p = exp2(0) = 1 would be wrong, so gate on the mask value itself
+                const float p = sacc[kb][e] > -0.5e30f ? exp2f(sacc[kb][e] - m_new) : 0.f;
+                sacc[kb][e] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+
+        // ---- O^T += V^T . P^T --------------------------------------------------------------------------
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            if constexpr (ES == 2) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    uint4 pf;
+                    pf.x = pack_bf16(sacc[kb][8 * s2 + 0], sacc[kb][8 * s2 + 1]);
+                    pf.y = pack_bf16(sacc[kb][8 * s2 + 2], sacc[kb][8 * s2 + 3]);
+                    pf.z = pack_bf16(sacc[kb][8 * s2 + 4], sacc[kb][8 * s2 + 5]);
+                    pf.w = pack_bf16(sacc[kb][8 * s2 + 6], sacc[kb][8 * s2 + 7]);
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d) {
+                        // A element j = V^T[d][key 16 s2 + 8 (j>>2) + 4 lh + (j&3)]
+                        const unsigned char *vr = ldsV + (d * 32 + lr) * VPITCH + (kb * 32 + 16 * s2 + 4 * lh) * 2;
+                        const uint2 lo = *reinterpret_cast<const uint2 *>(vr);
+                        const uint2 hi = *reinterpret_cast<const uint2 *>(vr + 16);
+                        const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
+                                                                         __builtin_bit_cast(bf16x8, pf), oacc[d], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d) {
+                        // A for MFMA step i = 4 g4 + e: V^T[d][key (e) + 8 g4 + 4 lh]
+                        const f32x4 v4 = *reinterpret_cast<const f32x4 *>(ldsV + (d * 32 + lr) * VPITCH + (kb * 32 + 8 * g4 + 4 * lh) * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(v4[e], sacc[kb][4 * g4 + e], oacc[d], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // ---- normalise and store: lane owns query my_q, registers hold d = db*32 + (e&3) + 8*(e>>2) + 4*lh ------
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (my_q < lq) {
+        T *orow = O + (size_t)my_q * a.ldo;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = d * 32 + 8 * g4 + 4 * lh;
+                if constexpr (FAST) {
+                    if (d0 < dh) {
+                        if constexpr (ES == 2) {
+                            uint2 p;
+                            p.x = pack_bf16(oacc[d][4 * g4 + 0] * inv, oacc[d][4 * g4 + 1] * inv);
+                            p.y = pack_bf16(oacc[d][4 * g4 + 2] * inv, oacc[d][4 * g4 + 3] * inv);
+                            *reinterpret_cast<uint2 *>(orow + d0) = p;
+                        } else {
+                            float4 p = make_float4(oacc[d][4 * g4 + 0] * inv, oacc[d][4 * g4 + 1] * inv,
+                                                   oacc[d][4 * g4 + 2] * inv, oacc[d][4 * g4 + 3] * inv);
+                            *reinterpret_cast<float4 *>(orow + d0) = p;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (d0 + e < dh) DT<T>::st(orow + d0 + e, oacc[d][4 * g4 + e] * inv);
+                }
+            }
+    }
+}
+
+template <typename T, int DHP>
+int launch(const AttnArgs &a, int B, int max_q, hipStream_t st) {
+    constexpr int EPC = 16 / sizeof(T);
+    const bool fast = (a.dh % EPC == 0) && (a.ldq % EPC == 0) && (a.ldk % EPC == 0) && (a.ldv % EPC == 0) && (a.ldo % EPC == 0) &&
+                      aligned16(a.q) && aligned16(a.k) && aligned16(a.v) && aligned16(a.out);
+    dim3 grid(cdiv(max_q, QB), a.H, B);
+    if (fast)
+        hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, true>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, false>), grid, dim3(256), 0, st, a);
+    ACAI_LAUNCH_CHECK("acai_attn_varlen_fwd");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int acai_attn_varlen_fwd(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, void *out, int ldo,
+                                    const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int causal,
+                                    int dtype, void *stream) {
+    ACAI_CHECK_ARG(q && k && v && out && cu_q && cu_k, "acai_attn_varlen_fwd: null operand");
+    ACAI_CHECK_ARG(B > 0 && H > 0 && dh > 0 && dh <= 64 && max_q > 0, "acai_attn_varlen_fwd: bad dims B=%d H=%d dh=%d max_q=%d (dh <= 64)", B, H, dh, max_q);
+    ACAI_CHECK_ARG(ldq >= H * dh && ldk >= H * dh && ldv >= H * dh && ldo >= H * dh, "acai_attn_varlen_fwd: row stride smaller than H*dh");
+    ACAI_CHECK_ARG(B <= 65535 && H <= 65535, "acai_attn_varlen_fwd: grid too large");
+    AttnArgs a{q, k, v, out, cu_q, cu_k, ldq, ldk, ldv, ldo, H, dh, causal, 0.f};
+    a.scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ACAI_BF16) return dh <= 32 ? launch<bf16_t, 32>(a, B, max_q, st) : launch<bf16_t, 64>(a, B, max_q, st);
+    if (dtype == ACAI_F32) return dh <= 32 ? launch<float, 32>(a, B, max_q, st) : launch<float, 64>(a, B, max_q, st);
+    return acai_set_err(-1, "acai_attn_varlen_fwd: bad dtype %d", dtype);
+}

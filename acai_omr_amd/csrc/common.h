@@ -1,0 +1,66 @@
+// Shared device/host helpers for the gfx950 kernels.  CDNA4 only: wave = 64 lanes, MFMA 32x32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/acai_omr_hip.h"
+
+typedef uint16_t bf16_t;  // raw bf16 storage
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+extern char g_acai_err[512];
+int acai_set_err(int code, const char *fmt, ...);
+
+#define ACAI_CHECK_ARG(cond, ...)                       \
+    do {                                                \
+        if (!(cond)) return acai_set_err(-1, __VA_ARGS__); \
+    } while (0)
+
+#define ACAI_LAUNCH_CHECK(name)                                                        \
+    do {                                                                               \
+        hipError_t e_ = hipGetLastError();                                             \
+        if (e_ != hipSuccess) return acai_set_err((int)e_, "%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- bf16 <-> f32 (round-to-nearest-even; plain casts keep NaN a NaN on gfx950) --------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ float round_bf16(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+// exact-erf GELU, as torch's F.gelu(approximate="none")
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <typename T> struct DT;
+template <> struct DT<float> {
+    static constexpr int id = ACAI_F32;
+    __device__ static __forceinline__ float ld(const float *p) { return *p; }
+    __device__ static __forceinline__ void st(float *p, float v) { *p = v; }
+};
+template <> struct DT<bf16_t> {
+    static constexpr int id = ACAI_BF16;
+    __device__ static __forceinline__ float ld(const bf16_t *p) { return bf2f(*p); }
+    __device__ static __forceinline__ void st(bf16_t *p, float v) { *p = f2bf(v); }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }

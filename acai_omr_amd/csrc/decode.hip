@@ -1,0 +1,532 @@
+// KV-cached greedy decode step: the HBM-bound half of the path.
+// Reference: CachedTransformerDecoderLayer.cached_forward (acai_omr/models/kv_caching.py:190-223),
+// KVCache.update (K:83-109), CachedTransformerDecoder.cached_generate (K:292-302),
+// OMRDecoder.cached_generate (acai_omr/models/models.py:518-528), ViTOMR.cached_get_next_token (M:575-583),
+// cached_greedy_generate loop body (M:603-611).
+//
+// gfx950 design: per step the bytes that matter are the decoder weights (read once) and, dominating, the
+// cross-attention K/V of every sequence (12 layers x 2 x S x 1024 elements each).  Everything is a
+// streaming kernel with 16-byte loads, fp32 accumulation and no host involvement: positions, lengths and
+// the finished flags live in device memory, so one captured hipGraph replays for every token.
+//   skinny_gemm   : y[B,N] = x[B,K] . W[N,K]^T, 8 lanes per weight row (128 contiguous bytes per row per
+//                   wave instruction), x staged once per workgroup in LDS (bf16 or fp32), v_dot2_f32_bf16.
+//   decode_attn   : flash-decoding split over keys: grid (split, head, sequence), 8 lanes per key
+//                   (dh 64 bf16 = 128 B), online softmax per lane group, in-wave + LDS combine, one
+//                   (m, l, o[dh]) partial per workgroup; attn_combine merges the splits.
+#include "common.h"
+
+namespace {
+
+constexpr int SK_KC = 1024;  // k elements of x staged in LDS per pass
+constexpr int SK_BC = 8;     // batch rows per pass
+
+struct SkinnyArgs {
+    const float *x;        // [B, ldx] fp32
+    const void *W;         // [N, ldw]
+    const float *bias;     // [N] or null
+    const float *residual; // [B, ldr] or null
+    float *y;              // [B, ldy]
+    int ldx, ldw, ldr, ldy, B, N, K, flags;
+    // optional KV append (self-attention in_proj): columns E..3E also go to the caches at position step[1]
+    void *k_cache, *v_cache;
+    const int32_t *step;
+    int E, H, dh, dhp, Tmax;
+};
+
+template <typename TW, bool FAST>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
+    constexpr int ES = sizeof(TW), EPC = 16 / ES;
+    __shared__ __attribute__((aligned(16))) unsigned char xs_raw[SK_BC * SK_KC * ES];
+    TW *xs = reinterpret_cast<TW *>(xs_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = lane & 7, rsub = lane >> 3;
+    const int n = blockIdx.x * 32 + wave * 8 + rsub;
+    const TW *W = reinterpret_cast<const TW *>(a.W);
+    const bool row_ok = n < a.N;
+
+    for (int b0 = 0; b0 < a.B; b0 += SK_BC) {
+        const int nb = min(SK_BC, a.B - b0);
+        float acc[SK_BC];
+#pragma unroll
+        for (int b = 0; b < SK_BC; ++b) acc[b] = 0.f;
+        for (int k0 = 0; k0 < a.K; k0 += SK_KC) {
+            const int kc = min(SK_KC, a.K - k0);
+            __syncthreads();  // previous pass has finished reading xs
+            for (int i = tid; i < SK_BC * SK_KC; i += 256) {
+                const int b = i / SK_KC, k = i - b * SK_KC;
+                const float v = (b < nb && k < kc) ? a.x[(size_t)(b0 + b) * a.ldx + k0 + k] : 0.f;
+                DT<TW>::st(xs + i, v);  // bf16 mode: autocast's input cast
+            }
+            __syncthreads();
+            if (row_ok) {
+                const int nsteps = (kc + 8 * EPC - 1) / (8 * EPC);
+#pragma unroll 4
+                for (int s = 0; s < nsteps; ++s) {
+                    const int kl = (s * 8 + kq) * EPC;  // local k of this lane's chunk
+                    uint4 wv = make_uint4(0, 0, 0, 0);
+                    if constexpr (FAST) {
+                        if (kl < kc) wv = *reinterpret_cast<const uint4 *>(W + (size_t)n * a.ldw + k0 + kl);
+                    } else {
+                        union { uint4 v; TW e[EPC]; } u;
+                        u.v = wv;
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e)
+                            if (kl + e < kc) u.e[e] = W[(size_t)n * a.ldw + k0 + kl + e];
+                        wv = u.v;
+                    }
+#pragma unroll
+                    for (int b = 0; b < SK_BC; ++b) {
+                        const uint4 xv = *reinterpret_cast<const uint4 *>(xs + b * SK_KC + kl);
+                        if constexpr (ES == 2) {
+                            acc[b] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, wv.x), __builtin_bit_cast(bf16x2, xv.x), acc[b], false);
+                            acc[b] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, wv.y), __builtin_bit_cast(bf16x2, xv.y), acc[b], false);
+                            acc[b] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, wv.z), __builtin_bit_cast(bf16x2, xv.z), acc[b], false);
+                            acc[b] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, wv.w), __builtin_bit_cast(bf16x2, xv.w), acc[b], false);
+                        } else {
+                            const f32x4 w4 = __builtin_bit_cast(f32x4, wv), x4 = __builtin_bit_cast(f32x4, xv);
+                            acc[b] = fmaf(w4[0], x4[0], acc[b]);
+                            acc[b] = fmaf(w4[1], x4[1], acc[b]);
+                            acc[b] = fmaf(w4[2], x4[2], acc[b]);
+                            acc[b] = fmaf(w4[3], x4[3], acc[b]);
+                        }
+                    }
+                }
+            }
+        }
+        // reduce over the 8 lanes of a row; afterwards lane kq owns batch row b0 + kq
+        float mine = 0.f;
+#pragma unroll
+        for (int b = 0; b < SK_BC; ++b) {
+            float v = acc[b];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            if (kq == b) mine = v;
+        }
+        const int b = b0 + kq;
+        if (row_ok && kq < nb) {
+            float v = mine + (a.bias ? a.bias[n] : 0.f);
+            const bool rnd = a.flags & ACAI_GEMM_ROUND_BF16;
+            if (rnd) v = round_bf16(v);
+            if (a.flags & ACAI_GEMM_GELU) {
+                v = gelu_erf(v);
+                if (rnd) v = round_bf16(v);
+            }
+            if (a.k_cache && n >= a.E) {  // KVCache.update (K:94-95): position = entries already cached
+                const int kv = (n - a.E) / a.E, e = (n - a.E) - kv * a.E, hh = e / a.dh, dd = e - hh * a.dh;
+                const size_t off = (((size_t)b * a.H + hh) * a.Tmax + a.step[1]) * a.dhp + dd;
+                DT<TW>::st(reinterpret_cast<TW *>(kv ? a.v_cache : a.k_cache) + off, v);
+            }
+            if (a.residual) v += a.residual[(size_t)b * a.ldr + n];
+            a.y[(size_t)b * a.ldy + n] = v;
+        }
+    }
+}
+
+template <typename TW>
+int launch_skinny(const SkinnyArgs &a, hipStream_t st) {
+    constexpr int EPC = 16 / sizeof(TW);
+    const bool fast = (a.K % EPC == 0) && (a.ldw % EPC == 0) && aligned16(a.W);
+    dim3 grid(cdiv(a.N, 32));
+    if (fast)
+        hipLaunchKernelGGL((skinny_gemm_kernel<TW, true>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((skinny_gemm_kernel<TW, false>), grid, dim3(256), 0, st, a);
+    ACAI_LAUNCH_CHECK("skinny_gemm");
+    return 0;
+}
+
+// ---- decode attention ---------------------------------------------------------------------------------------
+struct DAttnArgs {
+    const float *q;   // [B, ldq] fp32, head h at column h*dh
+    const void *kc, *vc;
+    const int64_t *seq_off;  // per-sequence element offset (ragged cross K/V) or null
+    const int32_t *seq_len;  // per-sequence length (cross) or null
+    const int32_t *step;     // self-attention: length = step[1] + 1, layout [B][H][Tmax][dhp]
+    float *partial;          // [B][H][nsplit][dhp + 2]
+    int ldq, H, dh, dhp, Tmax, chunk, nsplit;
+    float scale_log2e;
+};
+
+template <typename TC, int LPK>  // LPK = lanes per key = dhp * sizeof(TC) / 16
+__global__ __launch_bounds__(256) void decode_attn_kernel(DAttnArgs a) {
+    constexpr int EPC = 16 / sizeof(TC), KPW = 64 / LPK, U = 4;
+    __shared__ float red[4][2 + 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = lane % LPK, kg = lane / LPK;
+    const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int len, hstride;
+    size_t base;
+    if (a.seq_off) {
+        len = a.seq_len[b];
+        hstride = len * a.dhp;
+        base = (size_t)a.seq_off[b] + (size_t)h * hstride;
+    } else {
+        len = a.step[1] + 1;
+        hstride = a.Tmax * a.dhp;
+        base = ((size_t)b * a.H + h) * hstride;
+    }
+    float *part = a.partial + (((size_t)b * a.H + h) * a.nsplit + split) * (a.dhp + 2);
+    const int c0 = split * a.chunk, c1 = min(len, c0 + a.chunk);
+    if (c0 >= len) {  // empty split: neutral element
+        if (tid < a.dhp + 2) part[tid] = tid == 0 ? -1.0e30f : 0.f;
+        return;
+    }
+    const TC *Kp = reinterpret_cast<const TC *>(a.kc) + base;
+    const TC *Vp = reinterpret_cast<const TC *>(a.vc) + base;
+
+    float qf[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const int d = kq * EPC + e;
+        qf[e] = d < a.dh ? a.q[(size_t)b * a.ldq + h * a.dh + d] : 0.f;
+    }
+    float m = -1.0e30f, l = 0.f, acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+
+    for (int key0 = c0 + wave * KPW + kg; key0 < c1; key0 += 4 * KPW * U) {
+        uint4 kk[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int key = key0 + u * 4 * KPW;
+            kk[u] = vv[u] = make_uint4(0, 0, 0, 0);
+            if (key < c1) {
+                kk[u] = *reinterpret_cast<const uint4 *>(Kp + (size_t)key * a.dhp + kq * EPC);
+                vv[u] = *reinterpret_cast<const uint4 *>(Vp + (size_t)key * a.dhp + kq * EPC);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int key = key0 + u * 4 * KPW;
+            float kf[EPC], vf[EPC];
+            if constexpr (sizeof(TC) == 2) {
+                const uint32_t kw[4] = {kk[u].x, kk[u].y, kk[u].z, kk[u].w}, vw[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    kf[2 * e] = __uint_as_float(kw[e] << 16);
+                    kf[2 * e + 1] = __uint_as_float(kw[e] & 0xffff0000u);
+                    vf[2 * e] = __uint_as_float(vw[e] << 16);
+                    vf[2 * e + 1] = __uint_as_float(vw[e] & 0xffff0000u);
+                }
+            } else {
+                const f32x4 k4 = __builtin_bit_cast(f32x4, kk[u]), v4 = __builtin_bit_cast(f32x4, vv[u]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    kf[e] = k4[e];
+                    vf[e] = v4[e];
+                }
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) s = fmaf(qf[e], kf[e], s);
+#pragma unroll
+            for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o);
+            if (key < c1) {  // uniform inside a lane group
+                s *= a.scale_log2e;
+                const float mn = fmaxf(m, s), al = exp2f(m - mn), p = exp2f(s - mn);
+                m = mn;
+                l = l * al + p;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[e] = acc[e] * al + p * vf[e];
+            }
+        }
+    }
+    // merge the KPW lane groups of this wave (lanes with equal kq)
+    float mw = m;
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) mw = fmaxf(mw, __shfl_xor(mw, o));
+    const float f = exp2f(m - mw);
+    l *= f;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] *= f;
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) {
+        l += __shfl_xor(l, o);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] += __shfl_xor(acc[e], o);
+    }
+    if (kg == 0) {
+        if (kq == 0) {
+            red[wave][0] = mw;
+            red[wave][1] = l;
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) red[wave][2 + kq * EPC + e] = acc[e];
+    }
+    __syncthreads();
+    if (tid < a.dhp + 2) {
+        const float M = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
+        if (tid == 0) {
+            part[0] = M;
+        } else {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += red[w][tid] * exp2f(red[w][0] - M);
+            part[tid] = v;
+        }
+    }
+}
+
+// one wave per (b, h): out[b, h*dh + d] = sum_s o_s[d] 2^(m_s - M) / sum_s l_s 2^(m_s - M)
+__global__ __launch_bounds__(64) void attn_combine_kernel(const float *partial, float *out, int ldo, int H, int dh, int dhp,
+                                                          int nsplit, int round_out) {
+    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+    const float *p = partial + ((size_t)b * H + h) * nsplit * (dhp + 2);
+    float M = -1.0e30f;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, p[s * (dhp + 2)]);
+    float l = 0.f, o = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float w = exp2f(p[s * (dhp + 2)] - M);
+        l += p[s * (dhp + 2) + 1] * w;
+        if (d < dhp) o += p[s * (dhp + 2) + 2 + d] * w;
+    }
+    if (d < dh) {
+        float v = o / l;
+        if (round_out) v = round_bf16(v);  // SDPA output is bf16 under autocast
+        out[(size_t)b * ldo + h * dh + d] = v;
+    }
+}
+
+// x[b,:] = vocab_embedding[token_b] + pos_embedding[t]; token from `tokens` or seqs[b, t-1] (quirk Q1: M:576)
+__global__ __launch_bounds__(256) void embed_kernel(const float *emb, const float *pos, const int64_t *tokens, const int64_t *seqs,
+                                                    const int32_t *step, int max_len, float *x, int E) {
+    const int b = blockIdx.x, t = step[0];
+    const int64_t tok = tokens ? tokens[b] : seqs[(size_t)b * max_len + t - 1];
+    for (int i = threadIdx.x; i < E; i += 256) x[(size_t)b * E + i] = emb[(size_t)tok * E + i] + pos[(size_t)t * E + i];
+}
+
+__global__ void set_step_kernel(int32_t *step, int t) { step[0] = t; }
+
+// cached_get_next_token (M:579-581) + loop bookkeeping (M:606-611).  One workgroup, wave w takes rows w, w+4, ...
+__global__ __launch_bounds__(256) void argmax_logprob_kernel(const float *logits, int V, int B, int64_t *seqs, float *logprobs,
+                                                             int max_len, int32_t *step, int32_t *finished, int eos, int round_lp,
+                                                             int bookkeeping) {
+    __shared__ int unfinished[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = step[0];
+    int cnt = 0;
+    for (int b = wave; b < B; b += 4) {
+        const float *lg = logits + (size_t)b * V;
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = lane; i < V; i += 64) {
+            const float v = lg[i];
+            if (v > best) {  // strided scan keeps the lowest index per lane on ties
+                best = v;
+                bi = i;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {  // argmax, first index on ties (torch.argmax on CPU)
+            const float ov = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > best || (ov == best && oi < bi)) {
+                best = ov;
+                bi = oi;
+            }
+        }
+        float se = 0.f;
+        for (int i = lane; i < V; i += 64) se += expf(lg[i] - best);
+        se = wave_sum(se);
+        float lp = -logf(se);  // logit[argmax] - logsumexp
+        if (round_lp) lp = round_bf16(lp);
+        if (bookkeeping) {
+            int fin = finished[b];
+            if (bi == eos) fin = 1;
+            if (lane == 0) {
+                seqs[(size_t)b * max_len + t] = bi;
+                logprobs[(size_t)b * max_len + t] = lp;
+                finished[b] = fin;
+            }
+            cnt += fin ? 0 : 1;
+        } else if (lane == 0) {
+            seqs[b] = bi;
+            logprobs[b] = lp;
+        }
+    }
+    if (lane == 0) unfinished[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (bookkeeping) finished[B] = unfinished[0] + unfinished[1] + unfinished[2] + unfinished[3];
+        step[0] = t + 1;
+        step[1] = step[1] + 1;
+    }
+}
+
+__global__ void advance_cache_kernel(int32_t *step) { step[1] = step[1] + 1; }
+
+template <typename TC>
+int launch_dattn(const DAttnArgs &a, int B, hipStream_t st) {
+    const int lpk = a.dhp * (int)sizeof(TC) / 16;
+    dim3 grid(a.nsplit, a.H, B);
+    switch (lpk) {
+        case 1: hipLaunchKernelGGL((decode_attn_kernel<TC, 1>), grid, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((decode_attn_kernel<TC, 2>), grid, dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((decode_attn_kernel<TC, 4>), grid, dim3(256), 0, st, a); break;
+        case 8: hipLaunchKernelGGL((decode_attn_kernel<TC, 8>), grid, dim3(256), 0, st, a); break;
+        case 16: hipLaunchKernelGGL((decode_attn_kernel<TC, 16>), grid, dim3(256), 0, st, a); break;
+        default: return acai_set_err(-1, "decode_attn: dhp=%d unsupported", a.dhp);
+    }
+    ACAI_LAUNCH_CHECK("decode_attn");
+    return 0;
+}
+
+int check_decoder(const AcaiDecoder *d) {
+    ACAI_CHECK_ARG(d && d->layers, "decoder: null descriptor");
+    ACAI_CHECK_ARG(d->B > 0 && d->L > 0 && d->E == d->H * d->dh && d->dhp >= d->dh && d->dhp <= 64 && (d->dhp & (d->dhp - 1)) == 0 &&
+                       d->dhp * (d->dtype == ACAI_BF16 ? 2 : 4) >= 16,
+                   "decoder: bad dims B=%d L=%d E=%d H=%d dh=%d dhp=%d", d->B, d->L, d->E, d->H, d->dh, d->dhp);
+    ACAI_CHECK_ARG(d->dtype == ACAI_F32 || d->dtype == ACAI_BF16, "decoder: bad dtype");
+    ACAI_CHECK_ARG(d->self_chunk > 0 && d->cross_chunk > 0 && d->self_nsplit > 0 && d->cross_nsplit > 0 &&
+                       (long)d->self_chunk * d->self_nsplit >= d->Tmax,
+                   "decoder: attention split does not cover the cache");
+    ACAI_CHECK_ARG(d->cross_off && d->cross_len && d->step && d->x && d->xn && d->qkv && d->attn && d->proj && d->hid && d->partial,
+                   "decoder: null buffer");
+    return 0;
+}
+
+template <typename TW>
+int decode_core(const AcaiDecoder *d, const int64_t *tokens, hipStream_t st, bool do_embed = true, bool do_unembed = true) {
+    const int B = d->B, E = d->E, H = d->H, F = d->F;
+    const int rnd = (d->flags & ACAI_GEMM_ROUND_BF16) ? ACAI_GEMM_ROUND_BF16 : 0;
+    const float sc = 1.4426950408889634f / sqrtf((float)d->dh);
+    int rc;
+    if (do_embed) {
+        hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, st, d->emb, d->pos, tokens, d->seqs, d->step, d->max_len, d->x, E);
+        ACAI_LAUNCH_CHECK("embed");
+    }
+
+    auto skinny = [&](const float *x, int ldx, const void *W, const float *bias, const float *res, float *y, int ldy, int N, int K,
+                      int flags, const AcaiDecLayer *kvl) -> int {
+        SkinnyArgs s{};
+        s.x = x; s.W = W; s.bias = bias; s.residual = res; s.y = y;
+        s.ldx = ldx; s.ldw = K; s.ldr = E; s.ldy = ldy; s.B = B; s.N = N; s.K = K; s.flags = flags;
+        if (kvl) {
+            s.k_cache = kvl->k_self; s.v_cache = kvl->v_self; s.step = d->step;
+            s.E = E; s.H = H; s.dh = d->dh; s.dhp = d->dhp; s.Tmax = d->Tmax;
+        }
+        return launch_skinny<TW>(s, st);
+    };
+    auto attend = [&](const float *q, int ldq, const void *kc, const void *vc, bool cross) -> int {
+        DAttnArgs a{};
+        a.q = q; a.kc = kc; a.vc = vc; a.ldq = ldq; a.H = H; a.dh = d->dh; a.dhp = d->dhp; a.Tmax = d->Tmax;
+        a.partial = d->partial; a.scale_log2e = sc;
+        if (cross) {
+            a.seq_off = d->cross_off; a.seq_len = d->cross_len; a.chunk = d->cross_chunk; a.nsplit = d->cross_nsplit;
+        } else {
+            a.step = d->step; a.chunk = d->self_chunk; a.nsplit = d->self_nsplit;
+        }
+        int r = launch_dattn<TW>(a, B, st);
+        if (r) return r;
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(H, B), dim3(64), 0, st, d->partial, d->attn, E, H, d->dh, d->dhp, a.nsplit, rnd ? 1 : 0);
+        ACAI_LAUNCH_CHECK("attn_combine");
+        return 0;
+    };
+
+    for (int l = 0; l < d->L; ++l) {
+        const AcaiDecLayer *ly = d->layers + l;
+        // self attention (K:193-208)
+        if ((rc = skinny(d->x, E, ly->self_in_w, ly->self_in_b, nullptr, d->qkv, 3 * E, 3 * E, E, rnd, ly))) return rc;
+        if ((rc = attend(d->qkv, 3 * E, ly->k_self, ly->v_self, false))) return rc;
+        if ((rc = skinny(d->attn, E, ly->self_out_w, ly->self_out_b, d->x, d->proj, E, E, E, rnd, nullptr))) return rc;
+        if ((rc = acai_layernorm_fwd(d->proj, ly->n1_w, ly->n1_b, 1e-5f, d->x, nullptr, B, E, st))) return rc;
+        // cross attention (K:212-220)
+        if ((rc = skinny(d->x, E, ly->cross_q_w, ly->cross_q_b, nullptr, d->qkv, 3 * E, E, E, rnd, nullptr))) return rc;
+        if ((rc = attend(d->qkv, 3 * E, ly->k_cross, ly->v_cross, true))) return rc;
+        if ((rc = skinny(d->attn, E, ly->cross_out_w, ly->cross_out_b, d->x, d->proj, E, E, E, rnd, nullptr))) return rc;
+        if ((rc = acai_layernorm_fwd(d->proj, ly->n2_w, ly->n2_b, 1e-5f, d->x, nullptr, B, E, st))) return rc;
+        // feed forward (K:222)
+        if ((rc = skinny(d->x, E, ly->lin1_w, ly->lin1_b, nullptr, d->hid, F, F, E, rnd | ACAI_GEMM_GELU, nullptr))) return rc;
+        if ((rc = skinny(d->hid, F, ly->lin2_w, ly->lin2_b, d->x, d->proj, E, E, F, rnd, nullptr))) return rc;
+        if ((rc = acai_layernorm_fwd(d->proj, ly->n3_w, ly->n3_b, 1e-5f, d->x, nullptr, B, E, st))) return rc;
+    }
+    if (d->fn_w) {
+        if ((rc = acai_layernorm_fwd(d->x, d->fn_w, d->fn_b, 1e-6f, d->xn, nullptr, B, E, st))) return rc;
+    } else {
+        hipError_t e = hipMemcpyAsync(d->xn, d->x, sizeof(float) * (size_t)B * E, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return acai_set_err((int)e, "hipMemcpyAsync: %s", hipGetErrorString(e));
+    }
+    if (do_unembed) {
+        SkinnyArgs s{};
+        s.x = d->xn; s.W = d->unembed_w; s.bias = d->unembed_b; s.y = d->logits;
+        s.ldx = E; s.ldw = E; s.ldy = d->V; s.B = B; s.N = d->V; s.K = E; s.flags = rnd;
+        if ((rc = launch_skinny<TW>(s, st))) return rc;
+    }
+    return 0;
+}
+
+}  // namespace
+
+// Stand-alone entry points for the module-level API (CachedMultiheadAttention.cached_forward K:123-140,
+// F.linear on (B,1,E) K:193,215): the same kernels acai_decode_step chains.
+extern "C" int acai_skinny_gemm(const float *x, int ldx, const void *W, int ldw, const float *bias, const float *residual, int ldr,
+                                float *y, int ldy, int B, int N, int K, int dtype, int flags, void *stream) {
+    ACAI_CHECK_ARG(x && W && y && B > 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && ldy >= N, "acai_skinny_gemm: bad arguments");
+    SkinnyArgs s{};
+    s.x = x; s.W = W; s.bias = bias; s.residual = residual; s.y = y;
+    s.ldx = ldx; s.ldw = ldw; s.ldr = ldr; s.ldy = ldy; s.B = B; s.N = N; s.K = K; s.flags = flags;
+    if (dtype == ACAI_BF16) return launch_skinny<bf16_t>(s, (hipStream_t)stream);
+    if (dtype == ACAI_F32) return launch_skinny<float>(s, (hipStream_t)stream);
+    return acai_set_err(-1, "acai_skinny_gemm: bad dtype %d", dtype);
+}
+
+extern "C" int acai_decode_attn(const float *q, int ldq, const void *kc, const void *vc, const int64_t *seq_off, const int32_t *seq_len,
+                                float *partial, float *out, int ldo, int B, int H, int dh, int dhp, int chunk, int nsplit, int dtype,
+                                int round_out, void *stream) {
+    ACAI_CHECK_ARG(q && kc && vc && seq_off && seq_len && partial && out, "acai_decode_attn: null operand");
+    ACAI_CHECK_ARG(B > 0 && H > 0 && dh > 0 && dhp >= dh && dhp <= 64 && (dhp & (dhp - 1)) == 0 && chunk > 0 && nsplit > 0,
+                   "acai_decode_attn: bad dims");
+    DAttnArgs a{};
+    a.q = q; a.kc = kc; a.vc = vc; a.seq_off = seq_off; a.seq_len = seq_len; a.partial = partial;
+    a.ldq = ldq; a.H = H; a.dh = dh; a.dhp = dhp; a.chunk = chunk; a.nsplit = nsplit;
+    a.scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = dtype == ACAI_BF16 ? launch_dattn<bf16_t>(a, B, st) : launch_dattn<float>(a, B, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(H, B), dim3(64), 0, st, partial, out, ldo, H, dh, dhp, nsplit, round_out);
+    ACAI_LAUNCH_CHECK("attn_combine");
+    return 0;
+}
+
+extern "C" int acai_decode_hidden(const AcaiDecoder *d, const float *x_in, void *stream) {
+    int rc = check_decoder(d);
+    if (rc) return rc;
+    ACAI_CHECK_ARG(x_in, "acai_decode_hidden: null input");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(d->x, x_in, sizeof(float) * (size_t)d->B * d->E, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return acai_set_err((int)e, "hipMemcpyAsync: %s", hipGetErrorString(e));
+    rc = d->dtype == ACAI_BF16 ? decode_core<bf16_t>(d, nullptr, st, false, false) : decode_core<float>(d, nullptr, st, false, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(advance_cache_kernel, dim3(1), dim3(1), 0, st, d->step);
+    ACAI_LAUNCH_CHECK("advance_cache");
+    return 0;
+}
+
+extern "C" int acai_decode_step(const AcaiDecoder *d, void *stream) {
+    int rc = check_decoder(d);
+    if (rc) return rc;
+    ACAI_CHECK_ARG(d->emb && d->pos && d->unembed_w && d->logits, "acai_decode_step: decoder has no embedding / unembed");
+    ACAI_CHECK_ARG(d->seqs && d->logprobs && d->finished && d->max_len > 1, "acai_decode_step: null sequence state");
+    hipStream_t st = (hipStream_t)stream;
+    rc = d->dtype == ACAI_BF16 ? decode_core<bf16_t>(d, nullptr, st) : decode_core<float>(d, nullptr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(argmax_logprob_kernel, dim3(1), dim3(256), 0, st, d->logits, d->V, d->B, d->seqs, d->logprobs, d->max_len, d->step,
+                       d->finished, d->eos, (d->flags & ACAI_GEMM_ROUND_BF16) ? 1 : 0, 1);
+    ACAI_LAUNCH_CHECK("argmax_logprob");
+    return 0;
+}
+
+extern "C" int acai_decode_logits(const AcaiDecoder *d, const int64_t *tokens, int time_step, void *stream) {
+    int rc = check_decoder(d);
+    if (rc) return rc;
+    ACAI_CHECK_ARG(d->emb && d->pos && d->unembed_w && d->logits, "acai_decode_logits: decoder has no embedding / unembed");
+    ACAI_CHECK_ARG(tokens && time_step >= 0 && time_step < d->Tmax, "acai_decode_logits: bad tokens / time_step %d", time_step);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(1), 0, st, d->step, time_step);
+    rc = d->dtype == ACAI_BF16 ? decode_core<bf16_t>(d, tokens, st) : decode_core<float>(d, tokens, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(advance_cache_kernel, dim3(1), dim3(1), 0, st, d->step);
+    ACAI_LAUNCH_CHECK("advance_cache");
+    return 0;
+}

@@ -1,0 +1,224 @@
+// C[M,N] = epi(A[M,K] . W[N,K]^T + bias) (+ residual): the nn.Linear of every projection on the path
+// (reference: acai_omr/models/models.py:29,57,204,205,428,655-660; kv_caching.py:193,215,244).
+//
+// gfx950 design: 128x128 block tile, 4 waves (2x2), each wave owns 64x64 = 2x2 MFMA 32x32 tiles in
+// 64 accumulator VGPRs.  Both operands are K-contiguous ("NT"), which is exactly the MFMA A/B lane
+// layout (lane (r,h) holds 8 consecutive k of row r), so A and W tiles are staged as 128-byte row
+// segments (bf16: BK = 64, fp32: BK = 32) with a 144-byte LDS pitch: ds_read_b128 of 32 rows at one
+// column offset is then bank-conflict free (36*r mod 64 distinct over each 16-lane group).
+// bf16 -> v_mfma_f32_32x32x16_bf16; fp32 -> v_mfma_f32_32x32x2_f32 (exact fp32 fma chain; one
+// ds_read_b128 feeds four K=2 MFMAs because lane-half h takes k = 8s+4h+j, j = 0..3).
+// Global -> register prefetch of tile t+1 is issued before the MFMAs of tile t (issue-early /
+// write-late staging), one LDS stage, ~3 workgroups per CU cover each other's barriers.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, ROWB = 128, PITCH = 144;
+
+struct GemmArgs {
+    const void *A, *W;
+    const float *bias, *residual;
+    void *C;
+    int lda, ldw, ldr, ldc, M, N, K, out_dtype, flags;
+    // EPI == 1 (cross K/V prefill scatter)
+    const int32_t *row_seq, *row_pos, *seq_len;
+    const int64_t *seq_off;
+    void *k_out, *v_out;
+    int E, dh, dhp;
+};
+
+template <typename T, bool FAST>
+__device__ __forceinline__ uint4 load_chunk(const T *base, int ld, int row, int rows, int k0, int K) {
+    constexpr int EPC = 16 / sizeof(T);
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (row >= rows) return r;
+    if constexpr (FAST) {
+        if (k0 < K) r = *reinterpret_cast<const uint4 *>(base + (size_t)row * ld + k0);
+    } else {
+        union { uint4 v; T e[EPC]; } u;
+        u.v = r;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+            if (k0 + e < K) u.e[e] = base[(size_t)row * ld + k0 + e];
+        r = u.v;
+    }
+    return r;
+}
+
+template <typename T, int EPI, bool FAST>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
+    constexpr int EPC = 16 / sizeof(T);     // elements per 16-byte chunk
+    constexpr int BK = ROWB / sizeof(T);    // k elements per tile
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(BM + BN) * PITCH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
+    // contiguous run of tiles along N (they share the same A panel in that XCD's L2).
+    const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BM - 1) / BM;
+    const int nwg = nbn * nbm;
+    int pid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = pid % 8, idx = pid / 8;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm0 = (pid / nbn) * BM, bn0 = (pid % nbn) * BN;
+
+    const T *A = reinterpret_cast<const T *>(g.A);
+    const T *W = reinterpret_cast<const T *>(g.W);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    uint4 ra[4], rb[4];
+    const int nkt = (g.K + BK - 1) / BK;
+
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, k0 = kt * BK + (c & 7) * EPC;
+            ra[i] = load_chunk<T, FAST>(A, g.lda, bm0 + row, g.M, k0, g.K);
+            rb[i] = load_chunk<T, FAST>(W, g.ldw, bn0 + row, g.N, k0, g.K);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, cb = (c & 7) * 16;
+            *reinterpret_cast<uint4 *>(lds + row * PITCH + cb) = ra[i];
+            *reinterpret_cast<uint4 *>(lds + (BM + row) * PITCH + cb) = rb[i];
+        }
+    };
+
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) load_tile(kt + 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            uint4 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = *reinterpret_cast<const uint4 *>(lds + (wm * 64 + i * 32 + lr) * PITCH + s * 32 + lh * 16);
+                fb[i] = *reinterpret_cast<const uint4 *>(lds + (BM + wn * 64 + i * 32 + lr) * PITCH + s * 32 + lh * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (sizeof(T) == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                                            __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+                    } else {
+                        const f32x4 a4 = __builtin_bit_cast(f32x4, fa[i]), b4 = __builtin_bit_cast(f32x4, fb[j]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) -----------------------
+    const bool do_gelu = g.flags & ACAI_GEMM_GELU, do_round = g.flags & ACAI_GEMM_ROUND_BF16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = bn0 + wn * 64 + j * 32 + lr;
+        if (col >= g.N) continue;
+        const float bv = g.bias ? g.bias[col] : 0.f;
+        int kv = 0, hh = 0, dd = 0;
+        if constexpr (EPI == 1) {
+            kv = col / g.E;
+            const int e = col - kv * g.E;
+            hh = e / g.dh;
+            dd = e - hh * g.dh;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = bm0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (row >= g.M) continue;
+                float v = acc[i][j][e] + bv;
+                if constexpr (EPI == 0) {
+                    if (do_round) v = round_bf16(v);
+                    if (do_gelu) {
+                        v = gelu_erf(v);
+                        if (do_round) v = round_bf16(v);
+                    }
+                    if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
+                    if (g.out_dtype == ACAI_BF16)
+                        reinterpret_cast<bf16_t *>(g.C)[(size_t)row * g.ldc + col] = f2bf(v);
+                    else
+                        reinterpret_cast<float *>(g.C)[(size_t)row * g.ldc + col] = v;
+                } else {
+                    const int b = g.row_seq[row], s = g.row_pos[row];
+                    const int64_t off = g.seq_off[b] + ((int64_t)hh * g.seq_len[b] + s) * g.dhp + dd;
+                    void *dst = kv ? g.v_out : g.k_out;
+                    if (g.out_dtype == ACAI_BF16)
+                        reinterpret_cast<bf16_t *>(dst)[off] = f2bf(v);
+                    else
+                        reinterpret_cast<float *>(dst)[off] = v;
+                }
+            }
+    }
+}
+
+template <typename T, int EPI>
+int launch(const GemmArgs &g, hipStream_t st) {
+    constexpr int EPC = 16 / sizeof(T);
+    const bool fast = (g.K % EPC == 0) && (g.lda % EPC == 0) && (g.ldw % EPC == 0) && aligned16(g.A) && aligned16(g.W);
+    const int nwg = cdiv(g.M, BM) * cdiv(g.N, BN);
+    if (fast)
+        hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, true>), dim3(nwg), dim3(256), 0, st, g);
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, false>), dim3(nwg), dim3(256), 0, st, g);
+    ACAI_LAUNCH_CHECK("acai_gemm_nt");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int acai_gemm_nt(const void *A, int lda, const void *W, int ldw, const float *bias, const float *residual, int ldr,
+                            void *C, int ldc, int M, int N, int K, int in_dtype, int out_dtype, int flags, void *stream) {
+    ACAI_CHECK_ARG(A && W && C, "acai_gemm_nt: null operand");
+    ACAI_CHECK_ARG(M >= 0 && N > 0 && K > 0, "acai_gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
+    ACAI_CHECK_ARG(lda >= K && ldw >= K && ldc >= N && (!residual || ldr >= N), "acai_gemm_nt: leading dimension smaller than row");
+    ACAI_CHECK_ARG((in_dtype == ACAI_F32 || in_dtype == ACAI_BF16) && (out_dtype == ACAI_F32 || out_dtype == ACAI_BF16),
+                   "acai_gemm_nt: bad dtype");
+    if (M == 0) return 0;
+    GemmArgs g{};
+    g.A = A; g.W = W; g.bias = bias; g.residual = residual; g.C = C;
+    g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.out_dtype = out_dtype; g.flags = flags;
+    return in_dtype == ACAI_BF16 ? launch<bf16_t, 0>(g, (hipStream_t)stream) : launch<float, 0>(g, (hipStream_t)stream);
+}
+
+extern "C" int acai_cross_kv_prefill(const void *mem, int ldm, const void *Wkv, int ldw, const float *bkv, const int32_t *row_seq,
+                                     const int32_t *row_pos, const int64_t *seq_off, const int32_t *seq_len, void *k_out,
+                                     void *v_out, int M, int E, int H, int dh, int dhp, int dtype, int flags, void *stream) {
+    ACAI_CHECK_ARG(mem && Wkv && row_seq && row_pos && seq_off && seq_len && k_out && v_out, "acai_cross_kv_prefill: null operand");
+    ACAI_CHECK_ARG(E == H * dh && dhp >= dh && ldm >= E && ldw >= E, "acai_cross_kv_prefill: bad dims E=%d H=%d dh=%d dhp=%d", E, H, dh, dhp);
+    ACAI_CHECK_ARG(dtype == ACAI_F32 || dtype == ACAI_BF16, "acai_cross_kv_prefill: bad dtype");
+    if (M == 0) return 0;
+    GemmArgs g{};
+    g.A = mem; g.W = Wkv; g.bias = bkv; g.lda = ldm; g.ldw = ldw; g.M = M; g.N = 2 * E; g.K = E;
+    g.out_dtype = dtype; g.flags = flags;
+    g.row_seq = row_seq; g.row_pos = row_pos; g.seq_off = seq_off; g.seq_len = seq_len; g.k_out = k_out; g.v_out = v_out;
+    g.E = E; g.dh = dh; g.dhp = dhp;
+    return dtype == ACAI_BF16 ? launch<bf16_t, 1>(g, (hipStream_t)stream) : launch<float, 1>(g, (hipStream_t)stream);
+}

@@ -1,0 +1,180 @@
+"""Thin tensor-level wrappers over the C ABI (include/acai_omr_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current stream; every FLOP of the path runs in
+the HIP library.  Every wrapper checks device / dtype / contiguity on the host before the launch (a
+faulting kernel can take the whole node down) and raises RuntimeError on a non-zero return code.
+"""
+import torch
+
+from . import _lib
+from ._lib import ACAI_BF16, ACAI_F32, GEMM_GELU, GEMM_ROUND_BF16  # noqa: F401
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return ACAI_BF16
+    if t.dtype == torch.float32:
+        return ACAI_F32
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _chk(t, name, dtype=None, rows_contig=True):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor (the product path has no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if rows_contig and t.dim() >= 1 and t.stride(-1) != 1:
+        raise ValueError(f"{name}: last dim must be contiguous")
+    return t
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def layernorm(x, w, b, eps, want_f32=True, want_bf16=False, out_f32=None):
+    _chk(x, "x", torch.float32)
+    assert x.is_contiguous() and x.dim() == 2
+    rows, dim = x.shape
+    y32 = (out_f32 if out_f32 is not None else torch.empty_like(x)) if want_f32 else None
+    y16 = torch.empty(rows, dim, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    assert w.numel() == dim and b.numel() == dim and w.dtype == torch.float32 and b.dtype == torch.float32
+    _lib.check(_lib.lib().acai_layernorm_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), float(eps), _p(y32), _p(y16), rows, dim, _st()),
+               "acai_layernorm_fwd")
+    return y32, y16
+
+
+def gemm_nt(a, w, bias=None, residual=None, out_dtype=torch.float32, gelu=False, round_bf16=False, out=None):
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias) (+ residual).  a, w share a dtype (fp32 or bf16); 2-D, row stride free."""
+    _chk(a, "a"), _chk(w, "w")
+    assert a.dim() == 2 and w.dim() == 2 and a.dtype == w.dtype and a.shape[1] == w.shape[1], (a.shape, w.shape, a.dtype, w.dtype)
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.shape == (M, N) and residual.stride(1) == 1
+    flags = (GEMM_GELU if gelu else 0) | (GEMM_ROUND_BF16 if round_bf16 else 0)
+    _lib.check(_lib.lib().acai_gemm_nt(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _p(bias), _p(residual),
+                                       residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0),
+                                       M, N, K, _dt(a), _dt(out), flags, _st()), "acai_gemm_nt")
+    return out
+
+
+def cast_bf16(x):
+    _chk(x, "x", torch.float32)
+    assert x.is_contiguous()
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().acai_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _st()), "acai_cast_f32_bf16")
+    return y
+
+
+def patchify(img, P, out, row0):
+    """img (1,H,W) fp32 -> rows row0.. of out [M, P*P]."""
+    _chk(img, "img", torch.float32)
+    assert img.dim() == 3 and img.shape[0] == 1 and img.is_contiguous()
+    H, W = img.shape[1], img.shape[2]
+    n = (H // P) * (W // P)
+    assert out.dim() == 2 and out.shape[1] == P * P and row0 + n <= out.shape[0] and out.stride(1) == 1
+    _lib.check(_lib.lib().acai_patchify(img.data_ptr(), H, W, P, out.data_ptr(), out.stride(0), row0, _dt(out), _st()), "acai_patchify")
+    return n
+
+
+def gather_rows(table, idx, add=None, out=None):
+    _chk(table, "table", torch.float32), _chk(idx, "idx", torch.int32)
+    assert table.dim() == 2 and table.is_contiguous() and idx.dim() == 1 and idx.is_contiguous()
+    rows, dim = idx.numel(), table.shape[1]
+    if out is None:
+        out = torch.empty(rows, dim, dtype=torch.float32, device=table.device)
+    assert out.is_contiguous() and out.shape == (rows, dim)
+    if add is not None:
+        assert add.shape == (rows, dim) and add.is_contiguous() and add.dtype == torch.float32
+    _lib.check(_lib.lib().acai_gather_rows(table.data_ptr(), idx.data_ptr(), _p(add), out.data_ptr(), rows, dim, _st()), "acai_gather_rows")
+    return out
+
+
+def attn_varlen(q, k, v, cu_q, cu_k, H, dh, max_q, causal=False, out=None):
+    """q [Mq, >=H*dh], k/v [Mk, >=H*dh] (2-D views with any row stride), cu_* int32 [B+1] on the GPU."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk(t, n)
+        assert t.dim() == 2 and t.dtype == q.dtype
+    _chk(cu_q, "cu_q", torch.int32), _chk(cu_k, "cu_k", torch.int32)
+    B = cu_q.numel() - 1
+    assert cu_k.numel() == B + 1
+    if out is None:
+        out = torch.empty(q.shape[0], H * dh, dtype=q.dtype, device=q.device)
+    assert out.shape[0] == q.shape[0] and out.stride(1) == 1 and out.dtype == q.dtype
+    _lib.check(_lib.lib().acai_attn_varlen_fwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+                                               out.data_ptr(), out.stride(0), cu_q.data_ptr(), cu_k.data_ptr(), B, H, dh, int(max_q),
+                                               1 if causal else 0, _dt(q), _st()), "acai_attn_varlen_fwd")
+    return out
+
+
+def cross_kv_prefill(mem, w_kv, b_kv, row_seq, row_pos, seq_off, seq_len, k_out, v_out, H, dh, dhp, round_bf16=False):
+    _chk(mem, "mem"), _chk(w_kv, "w_kv")
+    M, E = mem.shape
+    assert w_kv.shape == (2 * E, E) and mem.dtype == w_kv.dtype == k_out.dtype == v_out.dtype
+    assert row_seq.dtype == torch.int32 and row_pos.dtype == torch.int32 and seq_off.dtype == torch.int64 and seq_len.dtype == torch.int32
+    assert row_seq.numel() == M and row_pos.numel() == M
+    _lib.check(_lib.lib().acai_cross_kv_prefill(mem.data_ptr(), mem.stride(0), w_kv.data_ptr(), w_kv.stride(0), _p(b_kv), row_seq.data_ptr(),
+                                                row_pos.data_ptr(), seq_off.data_ptr(), seq_len.data_ptr(), k_out.data_ptr(), v_out.data_ptr(),
+                                                M, E, H, dh, dhp, _dt(mem), GEMM_ROUND_BF16 if round_bf16 else 0, _st()), "acai_cross_kv_prefill")
+
+
+def skinny_gemm(x, w, bias=None, residual=None, gelu=False, round_bf16=False, out=None):
+    """x [B,K] fp32, w [N,K] fp32 or bf16 -> y [B,N] fp32."""
+    _chk(x, "x", torch.float32), _chk(w, "w")
+    B, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if out is None:
+        out = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    flags = (GEMM_GELU if gelu else 0) | (GEMM_ROUND_BF16 if round_bf16 else 0)
+    _lib.check(_lib.lib().acai_skinny_gemm(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _p(bias), _p(residual),
+                                           residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0), B, N, K,
+                                           _dt(w), flags, _st()), "acai_skinny_gemm")
+    return out
+
+
+def decode_attn(q, kc, vc, seq_off, seq_len, H, dh, dhp, max_len, round_out=False, chunk=256):
+    """q [B, H*dh] fp32 (row stride free); kc/vc flat caches addressed by seq_off / seq_len (see header)."""
+    _chk(q, "q", torch.float32)
+    B = q.shape[0]
+    nsplit = max(1, -(-int(max_len) // chunk))
+    partial = torch.empty(B * H * nsplit * (dhp + 2), dtype=torch.float32, device=q.device)
+    out = torch.empty(B, H * dh, dtype=torch.float32, device=q.device)
+    _lib.check(_lib.lib().acai_decode_attn(q.data_ptr(), q.stride(0), kc.data_ptr(), vc.data_ptr(), seq_off.data_ptr(), seq_len.data_ptr(),
+                                           partial.data_ptr(), out.data_ptr(), out.stride(0), B, H, dh, dhp, chunk, nsplit, _dt(kc),
+                                           1 if round_out else 0, _st()), "acai_decode_attn")
+    return out
+
+
+class Graph:
+    """hipGraph capture/replay of whatever is enqueued on the current stream between begin() and end()."""
+
+    def __init__(self):
+        self.exec = None
+
+    def begin(self):
+        _lib.check(_lib.lib().acai_graph_begin(_st()), "acai_graph_begin")
+
+    def end(self):
+        import ctypes
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().acai_graph_end(_st(), ctypes.byref(h)), "acai_graph_end")
+        self.exec = h
+
+    def launch(self):
+        _lib.check(_lib.lib().acai_graph_launch(self.exec, _st()), "acai_graph_launch")
+
+    def __del__(self):
+        if self.exec is not None and _lib._lib is not None:
+            _lib._lib.acai_graph_destroy(self.exec)
+            self.exec = None

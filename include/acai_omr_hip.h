@@ -1,0 +1,139 @@
+/*
+ * acai_omr_hip.h - C ABI of the MI355X (gfx950) backend for the acai-omr model hot path.
+ *
+ * The reference (jsnchon/acai-omr) is pure Python on stock PyTorch: it has no FFI of its own.
+ * Each entry point below therefore replaces the stock ATen op sequence behind one reference
+ * call site (file:line cited per function; acai_omr/models/models.py = M, kv_caching.py = K).
+ * Callers own every buffer (PyTorch-ROCm tensors in practice); nothing here allocates, frees,
+ * synchronises or reads device memory on the host, so every call is hipGraph-capturable.
+ * All launches go to the hipStream_t passed as `stream` (void* in this header so that plain C /
+ * ctypes callers need no HIP headers).  Return value: 0 = ok, negative = argument error,
+ * positive = hipError_t; acai_last_error() gives a message.  No C++ exception crosses the ABI.
+ *
+ * dtypes: ACAI_F32 = fp32 storage + exact-fp32 MFMA (v_mfma_f32_32x32x2_f32);
+ *         ACAI_BF16 = bf16 storage + bf16 MFMA with fp32 accumulate.
+ * The residual stream, LayerNorm, softmax statistics, biases and logits are always fp32.
+ */
+#ifndef ACAI_OMR_HIP_H
+#define ACAI_OMR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACAI_ABI_VERSION 1
+#define ACAI_F32 0
+#define ACAI_BF16 1
+
+/* gemm epilogue flags */
+#define ACAI_GEMM_GELU 1       /* exact-erf GELU after bias (M:31 activation="gelu", M:657 nn.GELU) */
+#define ACAI_GEMM_ROUND_BF16 2 /* round (acc + bias) to bf16 first: restates autocast's bf16 linear output */
+
+int acai_version(void);
+const char *acai_last_error(void);
+
+/* nn.LayerNorm (M:33, eps 1e-6 final norms; torch TransformerEncoderLayer norm1/2/3 eps 1e-5).
+ * y = LN(x) * w + b over the last dim; out_f32 and/or out_bf16 may be NULL. */
+int acai_layernorm_fwd(const float *x, const float *w, const float *b, float eps, float *out_f32, void *out_bf16,
+                       int rows, int dim, void *stream);
+
+/* nn.Linear / F.linear (M:29,57,204,205,428,655-660; K:193,215,244):
+ * C[M,N] = epi(A[M,K] . W[N,K]^T + bias[N]) (+ residual[M,N]); A, W have dtype `in_dtype`,
+ * C has `out_dtype`; bias and residual are fp32 (NULL = absent). */
+int acai_gemm_nt(const void *A, int lda, const void *W, int ldw, const float *bias, const float *residual, int ldr,
+                 void *C, int ldc, int M, int N, int K, int in_dtype, int out_dtype, int flags, void *stream);
+
+/* MemoryCache.cache_memory_keys_and_vals (K:235-253): KV = mem . W_kv^T + b_kv with W_kv = rows E..3E of the
+ * cross-attention in_proj; written head-major and ragged for the decode kernels:
+ * k_out[seq_off[b] + (h*len[b] + s)*dhp + d], same for v_out; row_seq/row_pos give (b, s) of each memory row. */
+int acai_cross_kv_prefill(const void *mem, int ldm, const void *Wkv, int ldw, const float *bkv, const int32_t *row_seq,
+                          const int32_t *row_pos, const int64_t *seq_off, const int32_t *seq_len, void *k_out, void *v_out,
+                          int M, int E, int H, int dh, int dhp, int dtype, int flags, void *stream);
+
+/* nn.Unfold(P, stride P) on one (1,H,W) fp32 image, transposed to rows of P*P pixels (M:23,48-52);
+ * rows are written starting at out + row0*ld (dtype `out_dtype`). */
+int acai_patchify(const float *img, int H, int W, int P, void *out, int ld, int row0, int out_dtype, void *stream);
+
+/* out[i,:] = table[idx[i],:] (+ add[i,:]) : pos_embedding slices (M:50), nn.Embedding (M:460),
+ * MAE shuffle / restore index_select (M:114,123,229). table/out fp32. */
+int acai_gather_rows(const float *table, const int32_t *idx, const float *add, float *out, int rows, int dim, void *stream);
+
+/* autocast's fp32 -> bf16 input cast (round to nearest even) for an activation that feeds a bf16 GEMM. */
+int acai_cast_f32_bf16(const float *x, void *y, int64_t n, void *stream);
+
+/* F.scaled_dot_product_attention on packed ragged streams (torch nn.MultiheadAttention inside
+ * nn.TransformerEncoderLayer M:30-34,186-190 and nn.TransformerDecoderLayer M:422-426).
+ * q row i of sequence b is q + (cu_q[b]+i)*ldq + h*dh; same for k, v (cu_k) and out.
+ * causal != 0 applies the triu(diagonal=1) mask of M:468.  dh <= 64. */
+int acai_attn_varlen_fwd(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, void *out, int ldo,
+                         const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int causal,
+                         int dtype, void *stream);
+
+/* ---- KV-cached greedy decode (K:190-223, K:292-302, M:518-528, M:575-583) ------------------------------- */
+typedef struct {
+    const void *self_in_w;   const float *self_in_b;   /* self_attn.in_proj_{weight,bias} [3E,E] */
+    const void *self_out_w;  const float *self_out_b;  /* self_attn.out_proj */
+    const void *cross_q_w;   const float *cross_q_b;   /* rows 0..E of multihead_attn.in_proj (K:212-213) */
+    const void *cross_out_w; const float *cross_out_b; /* multihead_attn.out_proj */
+    const void *lin1_w;      const float *lin1_b;      /* linear1 [F,E] */
+    const void *lin2_w;      const float *lin2_b;      /* linear2 [E,F] */
+    const float *n1_w, *n1_b, *n2_w, *n2_b, *n3_w, *n3_b;
+    void *k_self, *v_self;              /* KVCache (K:35-41) as [Bmax][H][Tmax][dhp] */
+    const void *k_cross, *v_cross;      /* acai_cross_kv_prefill output */
+} AcaiDecLayer;
+
+typedef struct {
+    int32_t B, E, H, dh, dhp, F, V, L, Tmax, dtype, flags, max_len;
+    int32_t self_chunk, cross_chunk;    /* keys per attention workgroup */
+    int32_t self_nsplit, cross_nsplit;  /* workgroups per (b, h) */
+    int32_t bos, pad, eos, reserved;
+    const AcaiDecLayer *layers;         /* host array of L entries */
+    const float *emb;                   /* vocab_embedding.weight [V,E] fp32 */
+    const float *pos;                   /* decoder pos_embedding [Tmax,E] fp32 */
+    const float *fn_w, *fn_b;           /* decoder_blocks.norm (eps 1e-6) */
+    const void *unembed_w;              /* [V,E] in `dtype` */
+    const float *unembed_b;
+    const int64_t *cross_off;           /* [B] element offset of sequence b in k_cross / v_cross */
+    const int32_t *cross_len;           /* [B] memory length S_b */
+    int64_t *seqs;                      /* [B,max_len] token ids, seqs[:,0] = <bos> (M:568-569) */
+    float *logprobs;                    /* [B,max_len] (M:570) */
+    int32_t *step;                      /* device scalar t: next position to fill (starts at 1) */
+    int32_t *finished;                  /* [B] flags + [B] = count of unfinished rows after the step */
+    float *x, *xn, *qkv, *attn, *proj, *hid, *logits, *partial; /* workspaces, see DESIGN.md */
+} AcaiDecoder;
+
+/* One greedy step t = *step for all B rows: embed seqs[:,t-1] with pos_embedding[t] (quirk Q1, M:576),
+ * 12x cached_forward, final norm, unembed, argmax + log_softmax gather, seqs[:,t] / logprobs[:,t] update,
+ * finished flags, ++*step.  Enqueues only kernels: capture it in a hipGraph and replay. */
+int acai_decode_step(const AcaiDecoder *dec, void *stream);
+/* The same without the token bookkeeping: logits for caller-supplied tokens/time_step (OMRDecoder.cached_generate). */
+int acai_decode_logits(const AcaiDecoder *dec, const int64_t *tokens, int time_step, void *stream);
+
+/* CachedTransformerDecoder.cached_generate (K:292-302): x_in [B,E] fp32 is this step's embedding; the hidden state after
+ * the L cached layers and the optional final norm lands in dec->xn.  emb / pos / unembed may be NULL for this call. */
+int acai_decode_hidden(const AcaiDecoder *dec, const float *x_in, void *stream);
+
+/* F.linear on a (B,1,K) activation (K:193,215; nn.Linear inside cached_forward K:139,222): y[B,N] = x[B,K].W[N,K]^T
+ * + bias (+GELU) (+residual); x, y, bias, residual fp32, W in `dtype` (bf16: x is rounded to bf16 first, as autocast does). */
+int acai_skinny_gemm(const float *x, int ldx, const void *W, int ldw, const float *bias, const float *residual, int ldr,
+                     float *y, int ldy, int B, int N, int K, int dtype, int flags, void *stream);
+
+/* CachedMultiheadAttention.cached_forward's SDPA (K:131-136) for one query per sequence:
+ * keys/values of sequence b, head h at kc/vc + seq_off[b] + (h*seq_len[b] + s)*dhp; out[b, h*dh + d] fp32.
+ * partial: workspace of B*H*nsplit*(dhp+2) floats; chunk*nsplit must cover max(seq_len). */
+int acai_decode_attn(const float *q, int ldq, const void *kc, const void *vc, const int64_t *seq_off, const int32_t *seq_len,
+                     float *partial, float *out, int ldo, int B, int H, int dh, int dhp, int chunk, int nsplit, int dtype,
+                     int round_out, void *stream);
+
+/* hipGraph helpers (capture on `stream`, replay). */
+int acai_graph_begin(void *stream);
+int acai_graph_end(void *stream, void **graph_exec_out);
+int acai_graph_launch(void *graph_exec, void *stream);
+int acai_graph_destroy(void *graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,98 @@
+"""CPU-side checks (no GPU): the C-ABI library builds/loads and exports every symbol include/acai_omr_hip.h declares;
+host logic of the mirror modules (state_dict compatibility with reference checkpoints, error behaviour, integer
+bookkeeping)."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT, VOCAB, load_golden
+
+
+def test_library_exports_every_declared_symbol():
+    from acai_omr_amd import _lib
+    _lib.build()
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "acai_omr_hip.h")).read()
+    declared = set(re.findall(r"\b(acai_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert L.acai_version() == 1
+
+
+def test_struct_layouts_match_header():
+    """ctypes mirrors of AcaiDecLayer / AcaiDecoder: field order and count as in the header."""
+    from acai_omr_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "acai_omr_hip.h")).read()
+    body = hdr[hdr.index("typedef struct {"):hdr.index("} AcaiDecLayer;")]
+    names = re.findall(r"\*\s*([a-z0-9_]+)\s*[;,]", body)
+    names += []
+    assert [f for f, _ in _lib.AcaiDecLayer._fields_] == names
+    import ctypes
+    assert ctypes.sizeof(_lib.AcaiDecLayer) == 8 * len(names)
+    assert ctypes.sizeof(_lib.AcaiDecoder) == 20 * 4 + 8 * 21
+
+
+def test_ops_refuse_cpu_tensors():
+    """No CPU fallback: the product path fails loudly instead of computing on the host."""
+    from acai_omr_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.layernorm(torch.zeros(2, 8), torch.ones(8), torch.zeros(8), 1e-5)
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(torch.zeros(2, 8), torch.zeros(4, 8))
+
+
+def test_state_dict_keys_match_reference_checkpoints():
+    from acai_omr_amd.models.models import MAE, FineTuneOMREncoder, OMRDecoder, TeacherForcedViTOMR
+    fx = load_golden("vitomr_small")
+    cfg = fx["cfg"]
+    enc = FineTuneOMREncoder(cfg["P"], cfg["pe_h"], cfg["pe_w"], cfg["ft_depth"], num_layers=cfg["enc_layers"], hidden_dim=cfg["enc_dim"],
+                             num_heads=cfg["enc_heads"], mlp_dim=cfg["enc_mlp"])
+    dec = OMRDecoder(cfg["max_len"], VOCAB, num_layers=cfg["dec_layers"], hidden_dim=cfg["dec_dim"], num_heads=cfg["dec_heads"], mlp_dim=cfg["dec_mlp"])
+    m = TeacherForcedViTOMR(enc, None, dec, transition_head_dim=cfg["head_dim"])
+    assert set(m.state_dict().keys()) == set(fx["state_dict"].keys())
+    m.load_state_dict(fx["state_dict"])
+    cached = dec.to_cached_version(4, torch.bfloat16)
+    assert set(cached.state_dict().keys()) == set(dec.state_dict().keys())   # caches are non-persistent
+    # the reference's own debug checkpoint (debug_pretrained_mae.pth, 61 tensors)
+    dbg = load_golden("mae_debug_ckpt")
+    mae = MAE(0.75, 16, 60, 200, encoder_hidden_dim=10, decoder_hidden_dim=10, encoder_kwargs=dict(num_layers=2, num_heads=1, mlp_dim=1),
+              decoder_kwargs=dict(num_layers=2, num_heads=1, mlp_dim=1))
+    assert len(dbg["state_dict"]) == 61
+    mae.load_state_dict(dbg["state_dict"])
+    # MAE -> OMR encoder transfer (models.py:679-713) incl. frozen / fine-tune split and renumbering
+    enc2 = FineTuneOMREncoder(16, 60, 200, 1, num_layers=2, hidden_dim=10, num_heads=1, mlp_dim=1)
+    dec2 = OMRDecoder(16, VOCAB, num_layers=1, hidden_dim=8, num_heads=1, mlp_dim=4)
+    tf = TeacherForcedViTOMR(enc2, dbg["state_dict"], dec2, transition_head_dim=6)
+    assert torch.equal(tf.encoder.frozen_blocks.layers[0].linear1.weight, dbg["state_dict"]["encoder.encoder_blocks.layers.0.linear1.weight"])
+    assert torch.equal(tf.encoder.fine_tune_blocks.layers[0].linear1.weight, dbg["state_dict"]["encoder.encoder_blocks.layers.1.linear1.weight"])
+    assert torch.equal(tf.encoder.fine_tune_blocks.norm.weight, dbg["state_dict"]["encoder.encoder_blocks.norm.weight"])
+    # freezing rules (models.py:667-677)
+    assert not tf.encoder.pos_embedding.requires_grad and not tf.encoder.projection.weight.requires_grad
+    assert all(not p.requires_grad for p in tf.encoder.frozen_blocks.parameters())
+    assert all(p.requires_grad for p in tf.encoder.fine_tune_blocks.parameters())
+    groups, lrs = tf.create_fine_tune_param_groups(1e-4, 1e-5, 0.9)
+    assert len(groups) == 2 + 1 + 3 and lrs == [1e-5]
+
+
+def test_host_bookkeeping_kats():
+    from acai_omr_amd.models.models import OMRDecoder, ViTOMR, batchify_and_split_lmx_seqs
+    inp, tgt, mask = batchify_and_split_lmx_seqs((torch.tensor([0, 2, 3, 226]), torch.tensor([0, 2, 2, 3, 4, 226])), 1, "cpu")
+    assert inp.tolist() == [[0, 2, 3, 226, 1], [0, 2, 2, 3, 4]] and tgt.tolist() == [[2, 3, 226, 1, 1], [2, 2, 3, 4, 226]]
+    assert mask.int().tolist() == [[0, 0, 0, 0, 1], [0, 0, 0, 0, 0]]
+    dec = OMRDecoder(8, VOCAB, num_layers=1, hidden_dim=8, num_heads=1, mlp_dim=4)
+    assert (dec.bos_idx, dec.pad_idx, dec.eos_idx, dec.vocab_size) == (0, 1, 2, 227)
+    # PrepareLMXSequence KATs (tests/test_omr_teacher_force_train.py:22-28) are vocabulary lookups
+    assert [dec.tokens_to_idxs[t] for t in "measure key:fifths:-7 time".split()] == [3, 4, 19]
+    assert [dec.tokens_to_idxs[t] for t in "tremolo:4 C1".split()] == [226, 66]
+    v = ViTOMR(None, None, dec)
+    assert v.create_inference_mask(torch.tensor([[0, 2, 10, 2], [0, 20, 20, 2]])).int().tolist() == [[1, 1, 0, 0], [1, 1, 1, 1]]
+    s, lp, m = v.mask_and_clip_seqs(torch.tensor([[0, 5, 2, 7, 7], [0, 2, 9, 9, 9]]), torch.ones(2, 5))
+    assert s.tolist() == [[0, 5, 2], [0, 2, 1]] and lp.tolist() == [[1, 1, 1], [1, 1, 0]] and m.tolist() == [[True, True, True], [True, True, False]]
+    with pytest.raises(RuntimeError):
+        dec.prepare_caches(torch.zeros(1, 2, 8))
+    with pytest.raises(ValueError):
+        dec.forward(torch.zeros(1, 9, dtype=torch.long), torch.zeros(1, 2, 8), None, None)

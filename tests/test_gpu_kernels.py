@@ -1,0 +1,186 @@
+"""Kernel-level parity on the GPU: each C-ABI entry point against plain fp32 torch / the oracle on seeded inputs.
+fp32 kernels must agree to ~1e-5 (exact-fp32 MFMA); bf16 kernels are compared against the same math on bf16-rounded
+operands with fp32 accumulation (tolerance = a few bf16 ulps of the output)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from acai_omr_amd import _lib
+    _lib.lib()  # fails loudly if the HIP library is not built
+    return torch.device("cuda:0")
+
+
+def rb(x):
+    return x.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("rows,dim", [(5, 768), (33, 1024), (7, 10), (1, 512), (130, 12)])
+def test_layernorm(dev, rows, dim):
+    from acai_omr_amd import ops
+    g = torch.Generator().manual_seed(rows * dim)
+    x = torch.randn(rows, dim, generator=g) * 3 + 1
+    w, b = torch.randn(dim, generator=g), torch.randn(dim, generator=g)
+    y32, y16 = ops.layernorm(x.to(dev), w.to(dev), b.to(dev), 1e-5, want_bf16=True)
+    ref = torch.nn.functional.layer_norm(x, (dim,), w, b, 1e-5)
+    assert (y32.cpu() - ref).abs().max() < 2e-5
+    assert torch.equal(y16.cpu().float(), rb(y32.cpu()))
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (128, 128, 64), (37, 19, 10), (1, 227, 1024), (513, 768, 256), (260, 130, 72)])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_gemm_nt(dev, M, N, K, dtype):
+    from acai_omr_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    if dtype == "bf16":
+        a, w = rb(a), rb(w)
+        ad, wd = a.to(dev).to(torch.bfloat16), w.to(dev).to(torch.bfloat16)
+        tol = 3e-2
+    else:
+        ad, wd = a.to(dev), w.to(dev)
+        tol = 2e-5 * max(1.0, math.sqrt(K) / 8)
+    base = a.double() @ w.double().t() + bias.double()
+    # plain
+    y = ops.gemm_nt(ad, wd, bias.to(dev))
+    assert (y.cpu().double() - base).abs().max() < (tol if dtype == "fp32" else 1e-4 * K ** 0.5 + 1e-4)
+    # gelu + residual, fp32 out
+    y = ops.gemm_nt(ad, wd, bias.to(dev), residual=res.to(dev), gelu=True)
+    ref = torch.nn.functional.gelu(base.float()).double() + res.double()
+    assert (y.cpu().double() - ref).abs().max() < (tol if dtype == "fp32" else 1e-3)
+    # bf16 output with autocast-style rounding
+    y = ops.gemm_nt(ad, wd, bias.to(dev), out_dtype=torch.bfloat16, round_bf16=True)
+    err = (y.cpu().float().double() - base).abs() / (base.abs() + 1)
+    assert err.max() < 1e-2
+    # strided views (columns of a wider buffer), as the QKV split uses them
+    wide = torch.zeros(M, K + 24, device=dev, dtype=ad.dtype)
+    wide[:, 8:8 + K] = ad
+    y2 = ops.gemm_nt(wide[:, 8:8 + K], wd, bias.to(dev))
+    y1 = ops.gemm_nt(ad, wd, bias.to(dev))
+    assert torch.equal(y1, y2)
+
+
+def ref_attn(q, k, v, lens_q, lens_k, H, dh, causal):
+    out = torch.zeros(q.shape[0], H * dh, dtype=torch.float64)
+    oq = ok = 0
+    for lq, lk in zip(lens_q, lens_k):
+        for h in range(H):
+            sl = slice(h * dh, (h + 1) * dh)
+            s = q[oq:oq + lq, sl].double() @ k[ok:ok + lk, sl].double().t() / math.sqrt(dh)
+            if causal:
+                s = s.masked_fill(~torch.ones(lq, lk, dtype=torch.bool).tril(), float("-inf"))
+            out[oq:oq + lq, sl] = torch.softmax(s, -1) @ v[ok:ok + lk, sl].double()
+        oq += lq
+        ok += lk
+    return out
+
+
+@pytest.mark.parametrize("H,dh,lens_q,lens_k,causal", [
+    (2, 64, [8, 32, 200], None, False),
+    (3, 32, [130, 1, 77], None, False),
+    (2, 16, [65, 64], None, True),
+    (1, 6, [5, 9, 3], None, False),
+    (4, 12, [7, 12], [20, 13], False),     # cross attention: lq != lk
+    (2, 64, [300], None, True),
+    (12, 64, [1024], None, False),
+    (1, 10, [70], None, True),
+])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_attn_varlen(dev, H, dh, lens_q, lens_k, causal, dtype):
+    from acai_omr_amd import engine, ops
+    lens_k = lens_k or lens_q
+    g = torch.Generator().manual_seed(H * dh + sum(lens_q))
+    E = H * dh
+    qkv = torch.randn(sum(lens_q), 3 * E, generator=g)
+    kv = qkv if lens_k == lens_q else torch.randn(sum(lens_k), 3 * E, generator=g)
+    qkv[:, :E] *= 2.0  # spread the scores
+    if dtype == "bf16":
+        qkv, kv = rb(qkv), rb(kv)
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    qd, kd = qkv.to(dev).to(tdt), kv.to(dev).to(tdt)
+    cu_q, cu_k = engine.cu_from_lens(lens_q, dev), engine.cu_from_lens(lens_k, dev)
+    out = ops.attn_varlen(qd[:, :E], kd[:, E:2 * E], kd[:, 2 * E:], cu_q, cu_k, H, dh, max(lens_q), causal=causal)
+    ref = ref_attn(qkv[:, :E], kv[:, E:2 * E], kv[:, 2 * E:], lens_q, lens_k, H, dh, causal)
+    err = (out.cpu().double() - ref).abs().max()
+    assert err < (2e-5 if dtype == "fp32" else 2e-2), err
+
+
+def test_patchify_and_gather(dev):
+    from acai_omr_amd import ops
+    from oracle import vitomr_oracle as O
+    g = torch.Generator().manual_seed(3)
+    for (H, W, P) in [(32, 64, 16), (12, 20, 4), (48, 16, 16)]:
+        img = torch.rand(1, H, W, generator=g)
+        n = (H // P) * (W // P)
+        out = torch.zeros(n + 3, P * P, device=dev)
+        assert ops.patchify(img.to(dev), P, out, 2) == n
+        assert torch.equal(out[2:2 + n].cpu(), O.patchify(img, P)[0])
+        out16 = torch.zeros(n, P * P, device=dev, dtype=torch.bfloat16)
+        ops.patchify(img.to(dev), P, out16, 0)
+        assert torch.equal(out16.cpu().float(), rb(O.patchify(img, P)[0]))
+    table = torch.randn(50, 24, generator=g)
+    idx = torch.randint(0, 50, (33,), generator=g, dtype=torch.int32)
+    add = torch.randn(33, 24, generator=g)
+    assert torch.equal(ops.gather_rows(table.to(dev), idx.to(dev), add.to(dev)).cpu(), table[idx.long()] + add)
+    x = torch.randn(1000 + 3, generator=g)
+    assert torch.equal(ops.cast_bf16(x.to(dev)).cpu().float(), rb(x))
+
+
+@pytest.mark.parametrize("B,N,K", [(8, 3072, 1024), (3, 227, 1024), (1, 48, 12), (8, 1024, 4096), (11, 100, 2052), (2, 5, 1)])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_skinny_gemm(dev, B, N, K, dtype):
+    from acai_omr_amd import ops
+    g = torch.Generator().manual_seed(B + N + K)
+    x, w = torch.randn(B, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias, res = torch.randn(N, generator=g), torch.randn(B, N, generator=g)
+    if dtype == "bf16":
+        wd = w.to(dev).to(torch.bfloat16)
+        ref = (rb(x).double() @ rb(w).double().t() + bias.double())
+        y = ops.skinny_gemm(x.to(dev), wd, bias.to(dev), round_bf16=True)
+        # rounding to bf16 may flip on accumulation-order noise: allow one bf16 ulp
+        assert ((y.cpu().double() - rb(ref.float()).double()).abs() <= ref.abs() * 2 ** -7 + 1e-6).all()
+    else:
+        ref = x.double() @ w.double().t() + bias.double()
+        y = ops.skinny_gemm(x.to(dev), w.to(dev), bias.to(dev), residual=res.to(dev), gelu=True)
+        ref2 = torch.nn.functional.gelu(ref.float()).double() + res.double()
+        assert (y.cpu().double() - ref2).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("H,dh,lens", [(16, 64, [1024, 77, 4096, 1]), (2, 6, [3, 1]), (4, 12, [20, 16, 13]), (1, 32, [700])])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_decode_attn(dev, H, dh, lens, dtype):
+    from acai_omr_amd import ops
+    g = torch.Generator().manual_seed(H + dh + sum(lens))
+    B = len(lens)
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    dhp = 8 if dtype == "bf16" else 4
+    while dhp < dh:
+        dhp *= 2
+    q = torch.randn(B, H * dh, generator=g) * 2
+    ks = [torch.randn(H, l, dh, generator=g) for l in lens]
+    vs = [torch.randn(H, l, dh, generator=g) for l in lens]
+    if dtype == "bf16":
+        ks, vs = [rb(k) for k in ks], [rb(v) for v in vs]
+    total = sum(lens) * H * dhp
+    kc, vc = torch.zeros(total), torch.zeros(total)
+    offs, o = [], 0
+    for k, v, l in zip(ks, vs, lens):
+        offs.append(o)
+        kc[o:o + H * l * dhp].view(H, l, dhp)[..., :dh] = k
+        vc[o:o + H * l * dhp].view(H, l, dhp)[..., :dh] = v
+        o += H * l * dhp
+    out = ops.decode_attn(q.to(dev), kc.to(dev).to(tdt), vc.to(dev).to(tdt), torch.tensor(offs, dtype=torch.int64, device=dev),
+                          torch.tensor(lens, dtype=torch.int32, device=dev), H, dh, dhp, max(lens))
+    for b in range(B):
+        for h in range(H):
+            s = (q[b, h * dh:(h + 1) * dh].double() @ ks[b][h].double().t()) / math.sqrt(dh)
+            ref = torch.softmax(s, -1) @ vs[b][h].double()
+            assert (out[b, h * dh:(h + 1) * dh].cpu().double() - ref).abs().max() < 2e-5
