@@ -84,6 +84,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"acai_omr_amd: HIP extension {LIB_PATH} is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                            "there is no CPU fallback for the product path")
+    # ONE HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (soname libamdhip64.so.7, the same soname
+    # /opt/rocm's carries).  Load torch's copy first so that our NEEDED entry resolves to it; loading ours first would
+    # pull in /opt/rocm's runtime and torch would later add a second one (streams / events are not shared between them).
+    import torch
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(tl):
+        ctypes.CDLL(tl, mode=ctypes.RTLD_GLOBAL)
     L = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol

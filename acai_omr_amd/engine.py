@@ -162,6 +162,7 @@ class DecodeEngine:
         self.k_cross = self.v_cross = None
         self.cross_cap = 0
         self.graphs = {}
+        self.stream = torch.cuda.Stream(device=device)  # capture / replay stream (the legacy default stream cannot capture)
         self.B = 0
         self.lens = None
         self.cache_len = 0
@@ -289,12 +290,25 @@ class DecodeEngine:
         B, own = self.B, self.omr
         if max_len > self.Tmax:
             raise RuntimeError(f"{max_len} decoding steps is too long for max sequence length of {self.Tmax}")
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            out = self._greedy_on_stream(max_len, poll, use_graph, on_chunk)
+        cur.wait_stream(self.stream)
+        return out
+
+    def arm(self, B):
+        own = self.omr
         self.seqs[:B].fill_(own.pad_idx)
         self.seqs[:B, 0] = own.bos_idx
         self.logprobs[:B].zero_()
         self.finished.zero_()
         self.reset_self_cache()
         self.step.copy_(torch.tensor([1, 0], dtype=torch.int32))
+
+    def _greedy_on_stream(self, max_len, poll, use_graph, on_chunk):
+        B, own = self.B, self.omr
+        self.arm(B)
         st = ops._st()
         launch = None
         if use_graph:
@@ -304,10 +318,8 @@ class DecodeEngine:
                 # warm-up launch outside capture (first-use module load must not happen inside a capture), then re-arm
                 _lib.check(_lib.lib().acai_decode_step(ctypes.byref(self._desc), st), "acai_decode_step")
                 torch.cuda.current_stream().synchronize()
-                self.seqs[:B, 1:].fill_(own.pad_idx)
-                self.logprobs[:B].zero_()
-                self.finished.zero_()
-                self.step.copy_(torch.tensor([1, 0], dtype=torch.int32))
+                self.arm(B)
+                torch.cuda.current_stream().synchronize()
                 g = ops.Graph()
                 g.begin()
                 try:
