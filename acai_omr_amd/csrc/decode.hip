@@ -148,7 +148,10 @@ struct DAttnArgs {
     float scale_log2e;
 };
 
-template <typename TC, int LPK>  // LPK = lanes per key = dhp * sizeof(TC) / 16
+// LPK = lanes per key = dhp * sizeof(TC) / 16.  RAGGED = cross attention over the ragged encoder memory (the dominant
+// HBM stream of a decode step); !RAGGED = self attention over the [B][H][Tmax][dhp] cache.  Two instantiations so that
+// rocprof reports them as separate kernels.
+template <typename TC, int LPK, bool RAGGED>
 __global__ __launch_bounds__(256) void decode_attn_kernel(DAttnArgs a) {
     constexpr int EPC = 16 / sizeof(TC), KPW = 64 / LPK, U = 4;
     __shared__ float red[4][2 + 64];
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DAttnArgs a) {
     const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     int len, hstride;
     size_t base;
-    if (a.seq_off) {
+    if constexpr (RAGGED) {
         len = a.seq_len[b];
         hstride = len * a.dhp;
         base = (size_t)a.seq_off[b] + (size_t)h * hstride;
@@ -360,14 +363,16 @@ template <typename TC>
 int launch_dattn(const DAttnArgs &a, int B, hipStream_t st) {
     const int lpk = a.dhp * (int)sizeof(TC) / 16;
     dim3 grid(a.nsplit, a.H, B);
+#define ACAI_DA(L)                                                                                        \
+    case L:                                                                                               \
+        if (a.seq_off) hipLaunchKernelGGL((decode_attn_kernel<TC, L, true>), grid, dim3(256), 0, st, a);  \
+        else hipLaunchKernelGGL((decode_attn_kernel<TC, L, false>), grid, dim3(256), 0, st, a);           \
+        break;
     switch (lpk) {
-        case 1: hipLaunchKernelGGL((decode_attn_kernel<TC, 1>), grid, dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL((decode_attn_kernel<TC, 2>), grid, dim3(256), 0, st, a); break;
-        case 4: hipLaunchKernelGGL((decode_attn_kernel<TC, 4>), grid, dim3(256), 0, st, a); break;
-        case 8: hipLaunchKernelGGL((decode_attn_kernel<TC, 8>), grid, dim3(256), 0, st, a); break;
-        case 16: hipLaunchKernelGGL((decode_attn_kernel<TC, 16>), grid, dim3(256), 0, st, a); break;
+        ACAI_DA(1) ACAI_DA(2) ACAI_DA(4) ACAI_DA(8) ACAI_DA(16)
         default: return acai_set_err(-1, "decode_attn: dhp=%d unsupported", a.dhp);
     }
+#undef ACAI_DA
     ACAI_LAUNCH_CHECK("decode_attn");
     return 0;
 }
@@ -474,7 +479,7 @@ extern "C" int acai_skinny_gemm(const float *x, int ldx, const void *W, int ldw,
 extern "C" int acai_decode_attn(const float *q, int ldq, const void *kc, const void *vc, const int64_t *seq_off, const int32_t *seq_len,
                                 float *partial, float *out, int ldo, int B, int H, int dh, int dhp, int chunk, int nsplit, int dtype,
                                 int round_out, void *stream) {
-    ACAI_CHECK_ARG(q && kc && vc && seq_off && seq_len && partial && out, "acai_decode_attn: null operand");
+    ACAI_CHECK_ARG(q && kc && vc && seq_off && seq_len && partial, "acai_decode_attn: null operand");
     ACAI_CHECK_ARG(B > 0 && H > 0 && dh > 0 && dhp >= dh && dhp <= 64 && (dhp & (dhp - 1)) == 0 && chunk > 0 && nsplit > 0,
                    "acai_decode_attn: bad dims");
     DAttnArgs a{};
@@ -483,7 +488,7 @@ extern "C" int acai_decode_attn(const float *q, int ldq, const void *kc, const v
     a.scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
     hipStream_t st = (hipStream_t)stream;
     int rc = dtype == ACAI_BF16 ? launch_dattn<bf16_t>(a, B, st) : launch_dattn<float>(a, B, st);
-    if (rc) return rc;
+    if (rc || !out) return rc;  // out == NULL: partials only (lets a benchmark time the streaming kernel alone)
     hipLaunchKernelGGL(attn_combine_kernel, dim3(H, B), dim3(64), 0, st, partial, out, ldo, H, dh, dhp, nsplit, round_out);
     ACAI_LAUNCH_CHECK("attn_combine");
     return 0;

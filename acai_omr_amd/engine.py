@@ -306,28 +306,33 @@ class DecodeEngine:
         self.reset_self_cache()
         self.step.copy_(torch.tensor([1, 0], dtype=torch.int32))
 
+    def ensure_graph(self):
+        """hipGraph of one decode step for the current (B, cross split) configuration.  Must run on self.stream."""
+        B = self.B
+        key = (B, self.cross_nsplit)
+        g = self.graphs.get(key)
+        if g is None:
+            st = ops._st()
+            # warm-up launch outside capture (first-use code-object load must not happen inside a capture), then re-arm
+            _lib.check(_lib.lib().acai_decode_step(ctypes.byref(self._desc), st), "acai_decode_step")
+            torch.cuda.current_stream().synchronize()
+            self.arm(B)
+            torch.cuda.current_stream().synchronize()
+            g = ops.Graph()
+            g.begin()
+            try:
+                _lib.check(_lib.lib().acai_decode_step(ctypes.byref(self._desc), st), "acai_decode_step")
+            finally:
+                g.end()
+            self.graphs[key] = g
+        return g
+
     def _greedy_on_stream(self, max_len, poll, use_graph, on_chunk):
-        B, own = self.B, self.omr
+        B = self.B
         self.arm(B)
         st = ops._st()
-        launch = None
         if use_graph:
-            key = (B, self.cross_nsplit)
-            g = self.graphs.get(key)
-            if g is None:
-                # warm-up launch outside capture (first-use module load must not happen inside a capture), then re-arm
-                _lib.check(_lib.lib().acai_decode_step(ctypes.byref(self._desc), st), "acai_decode_step")
-                torch.cuda.current_stream().synchronize()
-                self.arm(B)
-                torch.cuda.current_stream().synchronize()
-                g = ops.Graph()
-                g.begin()
-                try:
-                    _lib.check(_lib.lib().acai_decode_step(ctypes.byref(self._desc), st), "acai_decode_step")
-                finally:
-                    g.end()
-                self.graphs[key] = g
-            launch = g.launch
+            launch = self.ensure_graph().launch
         else:
             launch = lambda: _lib.check(_lib.lib().acai_decode_step(ctypes.byref(self._desc), st), "acai_decode_step")  # noqa: E731
         done = 0

@@ -1,0 +1,193 @@
+"""Benchmark of the hot path on MI355X: LMX tokens/sec of KV-cached greedy decode (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 256 --warmup 32
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (config.workload): full-size ViTOMR (FineTuneOMREncoder ViT-B/16 + 12-layer d=1024 OMRDecoder, random init,
+seed 0), batch of 8 synthetic 512x2048 system images per GPU (4096 patches each), reference inference plumbing
+(encoder fp32, transition head + decode in bf16 with a bf16 KV cache).  A "step" is one greedy decode step of the
+whole batch (8 tokens per GPU), replayed from one captured hipGraph; inputs (cross K/V, weights) are resident in HBM
+before the timed region.  Encoder / head / cross-K/V prefill are timed once and reported separately (`prefill_ms`).
+Multi-GPU: images are independent -> each rank decodes its own batch of 8 (weak scaling), no data-path collective.
+
+One JSON line on rank 0 with `roofline` (dominant kernel: the cross-attention K/V stream, timed live with HIP events
+on the launch stream) and `cpu_baseline` (the CPU oracle on the host cores, bounded sample)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def build_model(device, batch, cache_dtype=torch.bfloat16):
+    from acai_omr_amd.inference.vitomr_inference import set_up_omr_inference
+    torch.manual_seed(0)
+    vitomr, _ = set_up_omr_inference(os.path.join(ROOT, "lmx_vocab.txt"), max_batch_size=batch, cache_dtype=cache_dtype, device=device)
+    return vitomr.eval()
+
+
+def time_cross_attn_kernel(eng, iters=48):
+    """Average duration of ONE launch of the dominant kernel (decode_attn_kernel<bf16, 8, RAGGED>), cycling over the 12
+    layers' K/V so that every launch streams from HBM as it does inside a step (12 x 134 MB >> 256 MB Infinity Cache)."""
+    import ctypes
+
+    from acai_omr_amd import _lib, ops
+    L = _lib.lib()
+    q = torch.randn(eng.B, 3 * eng.E, device=eng.device)
+    args = lambda l: (q.data_ptr(), q.stride(0), eng.k_cross[l].data_ptr(), eng.v_cross[l].data_ptr(), eng.cross_off.data_ptr(),  # noqa: E731
+                      eng.cross_len.data_ptr(), eng.partial.data_ptr(), None, 0, eng.B, eng.H, eng.dh, eng.dhp, eng.CROSS_CHUNK,
+                      eng.cross_nsplit, _lib.ACAI_BF16 if eng.bf else _lib.ACAI_F32, 0, ops._st())
+    for l in range(eng.L):
+        _lib.check(L.acai_decode_attn(*args(l)), "acai_decode_attn")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(iters):
+        _lib.check(L.acai_decode_attn(*args(i % eng.L)), "acai_decode_attn")
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3  # seconds per launch
+
+
+def cpu_baseline(vitomr, lens, steps):
+    """The CPU oracle (oracle/vitomr_oracle.py, "port") on the host cores: same weights, same batch shape, decode only."""
+    from oracle import vitomr_oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cores = min(cores, 16)  # the GPU box gives one GPU's job a 16-CPU share; more threads than that only adds contention
+    torch.set_num_threads(cores)
+    sd = {"decoder." + k: O.rbf16(v.detach().float().cpu()) if v.dim() >= 1 and "norm" not in k and "embedding" not in k else v.detach().float().cpu()
+          for k, v in vitomr.decoder.state_dict().items()}
+    O.WEIGHTS_PREROUNDED = True
+    try:
+        g = torch.Generator().manual_seed(0)
+        mem = O.rbf16(torch.randn(sum(lens), vitomr.decoder.hidden_dim, generator=g))
+        state = O.DecodeState(mem, lens, sd, vitomr.decoder.num_heads, "bf16")   # cross K/V prefill, untimed (as on the GPU)
+        B = len(lens)
+        tok = torch.zeros(B, dtype=torch.long)
+        logits = O.decode_step(state, tok, 1)  # warm-up step
+        t0 = time.perf_counter()
+        for t in range(2, 2 + steps):
+            tok, _ = O.next_token(logits, "bf16")
+            logits = O.decode_step(state, tok, t)
+        dt = time.perf_counter() - t0
+    finally:
+        O.WEIGHTS_PREROUNDED = False
+    return dict(value=B * steps / dt, unit="tokens/s", cores=cores, kind="port",
+                sample=f"{steps} greedy decode steps x {B} sequences (S={lens[0]}) after an untimed cross-K/V prefill; CPU oracle in its autocast(bf16) restatement, weights rounded once")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--encoder-dtype", default="fp32", choices=["fp32", "bf16"])
+    a = ap.parse_args()
+
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)   # RCCL; used for the barrier / max-reduce of the timing only
+
+    from torch.amp import autocast
+    vitomr = build_model(dev, a.batch)
+    g = torch.Generator().manual_seed(1000 + rank)
+    imgs = [torch.rand(1, a.height, a.width, generator=g).to(dev) for _ in range(a.batch)]
+
+    # ---- prefill (timed once, reported separately) ----------------------------------------------------------------------
+    with torch.no_grad():
+        def prefill():
+            with autocast(device_type="cuda", dtype=torch.bfloat16, enabled=a.encoder_dtype == "bf16"):
+                lat32, _, lens = vitomr.encoder.forward_packed(imgs)
+            with autocast(device_type="cuda", dtype=torch.bfloat16):
+                mem = vitomr.transition_head.forward_packed(lat32)
+            vitomr.decoder.decoder_blocks.prepare_caches_packed(None, mem, lens)
+            return lens
+        prefill()  # warm-up (code-object loads, allocator)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lens = prefill()
+        torch.cuda.synchronize()
+        prefill_s = time.perf_counter() - t0
+
+    eng = vitomr.decoder.decoder_blocks.engine(dev)
+    max_len = a.warmup + a.steps + 2
+    assert max_len <= eng.Tmax, "warmup + steps exceeds the 1536-token decoder"
+    cur = torch.cuda.current_stream(dev)
+    eng.stream.wait_stream(cur)
+    with torch.cuda.stream(eng.stream):
+        eng.arm(eng.B)
+        graph = eng.ensure_graph()
+        for _ in range(a.warmup):
+            graph.launch()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            graph.launch()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    cur.wait_stream(eng.stream)
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    tokens = world * a.batch * a.steps
+    assert int(eng.step[0].item()) == 1 + a.warmup + a.steps  # every replay advanced the device-side position
+
+    out = None
+    if rank == 0:
+        S = lens[0]
+        t_mid = a.warmup + a.steps // 2
+        # algorithmic bytes: weights once per step + per sequence 12*2*(S + t)*1024*2 B
+        w_bytes = sum(p.numel() for n, p in vitomr.decoder.named_parameters() if "decoder_blocks.layers" in n and p.dim() == 2) * 2 + \
+            vitomr.decoder.unembed.weight.numel() * 2
+        step_bytes = w_bytes + a.batch * 12 * 2 * (S + t_mid) * 1024 * 2
+        k_s = time_cross_attn_kernel(eng)
+        k_bytes = sum(lens) * 2 * eng.E * 2   # K and V rows of every sequence, bf16, one layer
+        roof = dict(bound="hbm", kernel="decode_attn_kernel<bf16,8,RAGGED> (cross-attention K/V stream, one layer, all sequences)",
+                    achieved=k_bytes / k_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=k_bytes / k_s / 1e9 / HBM_PEAK_GBS, traffic=None,
+                    kernel_us=k_s * 1e6, bytes_per_launch=k_bytes,
+                    step_bytes=step_bytes, step_achieved_GBs=step_bytes / (dt / a.steps) / 1e9)
+        out = dict(metric="LMX tokens/sec (greedy decode, KV cache)", value=tokens / dt, unit="tokens/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+                   ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
+                   config=dict(workload=f"vitomr_greedy_decode batch {a.batch}/GPU of {a.height}x{a.width} images ({S} patches), decode steps {a.warmup + 1}..{a.warmup + a.steps}",
+                               batch_per_gpu=a.batch, memory_len=S, decoder="12 x d1024 h16 mlp4096, V=227", hipgraph=True),
+                   prefill_ms=prefill_s * 1e3, prefill_encoder_dtype=a.encoder_dtype, roofline=roof)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(vitomr, lens, a.cpu_steps)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

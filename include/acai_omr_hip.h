@@ -122,7 +122,8 @@ int acai_skinny_gemm(const float *x, int ldx, const void *W, int ldw, const floa
 
 /* CachedMultiheadAttention.cached_forward's SDPA (K:131-136) for one query per sequence:
  * keys/values of sequence b, head h at kc/vc + seq_off[b] + (h*seq_len[b] + s)*dhp; out[b, h*dh + d] fp32.
- * partial: workspace of B*H*nsplit*(dhp+2) floats; chunk*nsplit must cover max(seq_len). */
+ * partial: workspace of B*H*nsplit*(dhp+2) floats; chunk*nsplit must cover max(seq_len).
+ * out == NULL stops after the split partials (m, l, o[dhp]) - the streaming kernel alone, for benchmarking. */
 int acai_decode_attn(const float *q, int ldq, const void *kc, const void *vc, const int64_t *seq_off, const int32_t *seq_len,
                      float *partial, float *out, int ldo, int B, int H, int dh, int dhp, int chunk, int nsplit, int dtype,
                      int round_out, void *stream);

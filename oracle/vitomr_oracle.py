@@ -51,10 +51,16 @@ def _r(x, prec):
     return rbf16(x) if prec == "bf16" else x
 
 
+WEIGHTS_PREROUNDED = False  # bench.py's cpu_baseline rounds the weights once (autocast caches its weight casts too)
+
+
 def linear(x, w, b, prec):
     """F.linear; under prec == "bf16" the autocast cast policy (inputs, weight and
     bias to bf16, fp32 accumulate, bf16 output)."""
     if prec == "bf16":
+        if WEIGHTS_PREROUNDED:
+            y = rbf16(x) @ w.t()
+            return rbf16(y if b is None else y + b)
         y = rbf16(x) @ rbf16(w).t()
         if b is not None:
             y = y + rbf16(b)
@@ -274,9 +280,10 @@ def decoder_forward_tf(inputs, mem, lens_t, lens_s, sd, num_heads, prec, prefix=
 
 
 class DecodeState:
-    """Self K/V caches (K:5-109) and cross K/V (K:227-256), one entry per layer, per sequence."""
+    """Self K/V caches (K:5-109) and cross K/V (K:227-256), one entry per layer.  Heads are batched into one matmul
+    per sequence so that the CPU baseline is not a Python-loop artefact."""
 
-    def __init__(self, mem, lens_s, sd, num_heads, prec, prefix="decoder."):
+    def __init__(self, mem, lens_s, sd, num_heads, prec, prefix="decoder.", t_cap=64):
         self.sd, self.num_heads, self.prec, self.prefix = sd, num_heads, prec, prefix
         self.lens_s = lens_s
         self.B = len(lens_s)
@@ -285,52 +292,63 @@ class DecodeState:
             self.L += 1
         E = sd[prefix + "pos_embedding"].shape[1]
         self.E = E
-        # MemoryCache.cache_memory_keys_and_vals (K:235-253): rows d..3d of the cross in_proj
+        H, dh = num_heads, E // num_heads
+        # MemoryCache.cache_memory_keys_and_vals (K:235-253): rows d..3d of the cross in_proj; stored (H, S_b, dh) per sequence
         self.k_cross, self.v_cross = [], []
         for l in range(self.L):
             p = f"{prefix}decoder_blocks.layers.{l}.multihead_attn."
             kv = linear(mem, sd[p + "in_proj_weight"][E:], sd[p + "in_proj_bias"][E:], prec)
-            self.k_cross.append(kv[:, :E])
-            self.v_cross.append(kv[:, E:])
-        self.k_self = [[] for _ in range(self.L)]  # list over steps of (B, E)
-        self.v_self = [[] for _ in range(self.L)]
+            ks, vs, o = [], [], 0
+            for ls in lens_s:
+                ks.append(kv[o:o + ls, :E].reshape(ls, H, dh).transpose(0, 1).contiguous())
+                vs.append(kv[o:o + ls, E:].reshape(ls, H, dh).transpose(0, 1).contiguous())
+                o += ls
+            self.k_cross.append(ks)
+            self.v_cross.append(vs)
+        self.t = 0
+        self.k_self = [torch.zeros(self.B, H, t_cap, dh) for _ in range(self.L)]
+        self.v_self = [torch.zeros(self.B, H, t_cap, dh) for _ in range(self.L)]
+
+    def _grow(self):
+        for c in (self.k_self, self.v_self):
+            for l in range(self.L):
+                c[l] = torch.cat([c[l], torch.zeros_like(c[l])], dim=2)
+
+
+def _sdpa_heads(q, K, V, prec):
+    """q (..., H, 1, dh), K/V (..., H, T, dh): softmax(q K^T / sqrt(dh)) V for every head at once, no mask (K:206)."""
+    s = (q @ K.transpose(-1, -2)) * (1.0 / math.sqrt(q.shape[-1]))
+    return _r(torch.softmax(s, dim=-1) @ V, prec)
 
 
 def decode_step(state, tokens, time_step):
     """OMRDecoder.cached_generate (M:518-528) + CachedTransformerDecoder.cached_generate
     (K:292-302) + layer.cached_forward (K:190-223).  tokens (B,), time_step indexes
     pos_embedding literally.  Returns logits (B, V)."""
-    sd, prec, H, E, px = state.sd, state.prec, state.num_heads, state.E, state.prefix
+    sd, prec, H, E, px, B = state.sd, state.prec, state.num_heads, state.E, state.prefix, state.B
     dh = E // H
+    if state.t >= state.k_self[0].shape[2]:
+        state._grow()
+    t = state.t
     x = sd[px + "vocab_embedding.weight"][tokens] + sd[px + "pos_embedding"][time_step]
     for l in range(state.L):
         p = f"{px}decoder_blocks.layers.{l}."
         qkv = linear(x, sd[p + "self_attn.in_proj_weight"], sd[p + "self_attn.in_proj_bias"], prec)
-        q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
-        state.k_self[l].append(k)
-        state.v_self[l].append(v)
-        K = torch.stack(state.k_self[l], 1)  # (B, t, E); no mask (K:206)
-        V = torch.stack(state.v_self[l], 1)
-        sa = torch.empty_like(q)
-        for b in range(state.B):
-            for h in range(H):
-                sl = slice(h * dh, (h + 1) * dh)
-                sa[b, sl] = sdpa(q[b:b + 1, sl], K[b, :, sl], V[b, :, sl], None, prec)[0]
+        q, k, v = (c.reshape(B, H, 1, dh) for c in (qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]))
+        state.k_self[l][:, :, t:t + 1] = k
+        state.v_self[l][:, :, t:t + 1] = v
+        sa = _sdpa_heads(q, state.k_self[l][:, :, :t + 1], state.v_self[l][:, :, :t + 1], prec).reshape(B, E)
         sa = linear(sa, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"], prec)
         x = layer_norm(x + sa, sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5)
         qc = linear(x, sd[p + "multihead_attn.in_proj_weight"][:E], sd[p + "multihead_attn.in_proj_bias"][:E], prec)
-        ca = torch.empty_like(qc)
-        o = 0
-        for b, ls in enumerate(state.lens_s):
-            for h in range(H):
-                sl = slice(h * dh, (h + 1) * dh)
-                ca[b, sl] = sdpa(qc[b:b + 1, sl], state.k_cross[l][o:o + ls, sl], state.v_cross[l][o:o + ls, sl], None, prec)[0]
-            o += ls
+        ca = torch.stack([_sdpa_heads(qc[b].reshape(H, 1, dh), state.k_cross[l][b], state.v_cross[l][b], prec).reshape(E)
+                          for b in range(B)])
         ca = linear(ca, sd[p + "multihead_attn.out_proj.weight"], sd[p + "multihead_attn.out_proj.bias"], prec)
         x = layer_norm(x + ca, sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5)
         h1 = gelu(linear(x, sd[p + "linear1.weight"], sd[p + "linear1.bias"], prec), prec)
         h2 = linear(h1, sd[p + "linear2.weight"], sd[p + "linear2.bias"], prec)
         x = layer_norm(x + h2, sd[p + "norm3.weight"], sd[p + "norm3.bias"], 1e-5)
+    state.t += 1
     x = layer_norm(x, sd[px + "decoder_blocks.norm.weight"], sd[px + "decoder_blocks.norm.bias"], 1e-6)
     return linear(x, sd[px + "unembed.weight"], sd[px + "unembed.bias"], prec)
 
