@@ -30,7 +30,7 @@ class AcaiDecoder(Structure):
         "self_chunk", "cross_chunk", "self_nsplit", "cross_nsplit", "bos", "pad", "eos", "reserved")] + [
         ("layers", POINTER(AcaiDecLayer))] + [(n, c_void_p) for n in (
             "emb", "pos", "fn_w", "fn_b", "unembed_w", "unembed_b", "cross_off", "cross_len", "seqs", "logprobs",
-            "step", "finished", "x", "xn", "qkv", "attn", "proj", "hid", "logits", "partial")]
+            "step", "finished", "x", "xn", "qkv", "attn", "proj", "hid", "logits", "partial", "stats")]
 
 
 _SIGNATURES = {

@@ -31,6 +31,12 @@ struct SkinnyArgs {
     void *k_cache, *v_cache;
     const int32_t *step;
     int E, H, dh, dhp, Tmax;
+    // optional fused LayerNorm (MFMA kernel only): x := LN(x) on load (dim == K); the per-row (mean, rstd) can be
+    // published for a later launch; residual := LN(residual) from published statistics
+    const float *ln_w, *ln_b;
+    float ln_eps;
+    float *stats_out;        // [B][2]
+    const float *rln_w, *rln_b, *rstats;
 };
 
 template <typename TW, bool FAST>
@@ -123,8 +129,145 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     }
 }
 
+// ---- bf16 weights: MFMA skinny GEMM ---------------------------------------------------------------------------
+// Workgroup = 16 weight rows x all of K; wave w owns K/4 of it, so every lane streams its 16-byte fragments of the
+// weight rows straight into VGPRs (8 loads in flight per lane) and v_mfma_f32_16x16x32_bf16 does the K reduction:
+// A = W[16 rows][32 k], B = x^T[32 k][16 batch columns] (activation rounded to bf16 on load = autocast's input cast),
+// D[row][batch] accumulates in fp32.  No cross-lane shuffles, no LDS staging of x; the 4 K-slices meet in LDS once.
+// Optional fusions remove the per-row LayerNorm launches of the decode step (post-LN: x = LN(z)): LN on load of the
+// activation, and LN of the residual from statistics a previous launch published.
+__global__ __launch_bounds__(256) void skinny_mfma_kernel(SkinnyArgs a) {
+    __shared__ float red[4][256];
+    __shared__ float stats[16][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int Kw = a.K >> 2, kbase = wave * Kw, nch = Kw >> 5;
+    const bool row_ok = n0 + r < a.N;
+    const bf16_t *Wrow = reinterpret_cast<const bf16_t *>(a.W) + (size_t)(row_ok ? n0 + r : 0) * a.ldw + kbase + 8 * q;
+
+    for (int bt = 0; bt < a.B; bt += 16) {
+        const int nb = min(16, a.B - bt);
+        if (a.ln_w) {
+            __syncthreads();
+            for (int b = wave; b < nb; b += 4) {
+                const float *xr = a.x + (size_t)(bt + b) * a.ldx;
+                float s = 0.f;
+                for (int i = lane * 4; i < a.K; i += 256) {
+                    const float4 v = *reinterpret_cast<const float4 *>(xr + i);
+                    s += (v.x + v.y) + (v.z + v.w);
+                }
+                const float mean = wave_sum(s) / (float)a.K;
+                float qq = 0.f;
+                for (int i = lane * 4; i < a.K; i += 256) {
+                    const float4 v = *reinterpret_cast<const float4 *>(xr + i);
+                    const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+                    qq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
+                const float rstd = 1.0f / sqrtf(wave_sum(qq) / (float)a.K + a.ln_eps);
+                if (lane == 0) {
+                    stats[b][0] = mean;
+                    stats[b][1] = rstd;
+                    if (a.stats_out && blockIdx.x == 0) {
+                        a.stats_out[(bt + b) * 2] = mean;
+                        a.stats_out[(bt + b) * 2 + 1] = rstd;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        const bool col_ok = r < nb;
+        const float *xrow = a.x + (size_t)(bt + (col_ok ? r : 0)) * a.ldx + kbase + 8 * q;
+        float mean = 0.f, rstd = 1.f;
+        if (a.ln_w && col_ok) {
+            mean = stats[r][0];
+            rstd = stats[r][1];
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < nch; c0 += 8) {
+            uint4 wf[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                wf[c] = make_uint4(0, 0, 0, 0);
+                if (c0 + c < nch && row_ok) wf[c] = *reinterpret_cast<const uint4 *>(Wrow + 32 * (c0 + c));
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (c0 + c < nch) {
+                    uint4 xf = make_uint4(0, 0, 0, 0);
+                    if (col_ok) {
+                        float4 x0 = *reinterpret_cast<const float4 *>(xrow + 32 * (c0 + c));
+                        float4 x1 = *reinterpret_cast<const float4 *>(xrow + 32 * (c0 + c) + 4);
+                        if (a.ln_w) {
+                            const int k = kbase + 8 * q + 32 * (c0 + c);
+                            const float4 w0 = *reinterpret_cast<const float4 *>(a.ln_w + k), w1 = *reinterpret_cast<const float4 *>(a.ln_w + k + 4);
+                            const float4 b0 = *reinterpret_cast<const float4 *>(a.ln_b + k), b1 = *reinterpret_cast<const float4 *>(a.ln_b + k + 4);
+                            x0.x = (x0.x - mean) * rstd * w0.x + b0.x; x0.y = (x0.y - mean) * rstd * w0.y + b0.y;
+                            x0.z = (x0.z - mean) * rstd * w0.z + b0.z; x0.w = (x0.w - mean) * rstd * w0.w + b0.w;
+                            x1.x = (x1.x - mean) * rstd * w1.x + b1.x; x1.y = (x1.y - mean) * rstd * w1.y + b1.y;
+                            x1.z = (x1.z - mean) * rstd * w1.z + b1.z; x1.w = (x1.w - mean) * rstd * w1.w + b1.w;
+                        }
+                        xf = make_uint4(pack_bf16(x0.x, x0.y), pack_bf16(x0.z, x0.w), pack_bf16(x1.x, x1.y), pack_bf16(x1.z, x1.w));
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[c]), __builtin_bit_cast(bf16x8, xf), acc, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave][lane * 4 + i] = acc[i];
+        __syncthreads();
+        if (wave == 0) {
+            // D layout: col (batch) = lane & 15, row (weight row) = 4 * (lane >> 4) + i
+            const int b = bt + r;
+            const bool rnd = a.flags & ACAI_GEMM_ROUND_BF16;
+            float rmean = 0.f, rrstd = 1.f;
+            if (a.rln_w && col_ok) {
+                rmean = a.rstats[b * 2];
+                rrstd = a.rstats[b * 2 + 1];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + 4 * q + i;
+                if (n >= a.N || !col_ok) continue;
+                float v = red[0][lane * 4 + i] + red[1][lane * 4 + i] + red[2][lane * 4 + i] + red[3][lane * 4 + i];
+                v += a.bias ? a.bias[n] : 0.f;
+                if (rnd) v = round_bf16(v);
+                if (a.flags & ACAI_GEMM_GELU) {
+                    v = gelu_erf(v);
+                    if (rnd) v = round_bf16(v);
+                }
+                if (a.k_cache && n >= a.E) {
+                    const int kv = (n - a.E) / a.E, e = (n - a.E) - kv * a.E, hh = e / a.dh, dd = e - hh * a.dh;
+                    const size_t off = (((size_t)b * a.H + hh) * a.Tmax + a.step[1]) * a.dhp + dd;
+                    reinterpret_cast<bf16_t *>(kv ? a.v_cache : a.k_cache)[off] = f2bf(v);
+                }
+                if (a.residual) {
+                    float rv = a.residual[(size_t)b * a.ldr + n];
+                    if (a.rln_w) rv = (rv - rmean) * rrstd * a.rln_w[n] + a.rln_b[n];
+                    v += rv;
+                }
+                a.y[(size_t)b * a.ldy + n] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static inline bool skinny_mfma_ok(const SkinnyArgs &a) {
+    return (a.K % 128 == 0) && (a.ldw % 8 == 0) && (a.ldx % 4 == 0) && aligned16(a.W) && aligned16(a.x) &&
+           (!a.ln_w || (aligned16(a.ln_w) && aligned16(a.ln_b)));
+}
+
 template <typename TW>
 int launch_skinny(const SkinnyArgs &a, hipStream_t st) {
+    if constexpr (sizeof(TW) == 2) {
+        if (skinny_mfma_ok(a)) {
+            hipLaunchKernelGGL(skinny_mfma_kernel, dim3(cdiv(a.N, 16)), dim3(256), 0, st, a);
+            ACAI_LAUNCH_CHECK("skinny_mfma");
+            return 0;
+        }
+    }
+    if (a.ln_w || a.rln_w) return acai_set_err(-1, "skinny_gemm: fused LayerNorm needs the bf16 MFMA path (K %% 128 == 0, 16-byte aligned operands)");
     constexpr int EPC = 16 / sizeof(TW);
     const bool fast = (a.K % EPC == 0) && (a.ldw % EPC == 0) && aligned16(a.W);
     dim3 grid(cdiv(a.N, 32));
@@ -429,6 +572,57 @@ int decode_core(const AcaiDecoder *d, const int64_t *tokens, hipStream_t st, boo
         return 0;
     };
 
+    // Fused path (bf16, MFMA skinny GEMM): the residual stream is kept PRE-LayerNorm (z) and every consumer applies the
+    // LayerNorm on load, so a layer is 6 GEMV + 2 attention (+2 combine) launches instead of 17.
+    SkinnyArgs probe{};
+    probe.x = d->x; probe.W = d->layers[0].self_in_w; probe.K = E; probe.ldw = E; probe.ldx = E;
+    const bool fused = sizeof(TW) == 2 && d->stats && skinny_mfma_ok(probe) && (F % 128 == 0);
+    auto skinny_ln = [&](const float *x, int ldx, const void *W, const float *bias, float *y, int ldy, int N, int K, int flags,
+                         const AcaiDecLayer *kvl, const float *lnw, const float *lnb, float *stats_out, const float *res,
+                         const float *rlnw, const float *rlnb, const float *rstats) -> int {
+        SkinnyArgs s{};
+        s.x = x; s.W = W; s.bias = bias; s.residual = res; s.y = y;
+        s.ldx = ldx; s.ldw = K; s.ldr = E; s.ldy = ldy; s.B = B; s.N = N; s.K = K; s.flags = flags;
+        s.ln_w = lnw; s.ln_b = lnb; s.ln_eps = 1e-5f; s.stats_out = stats_out; s.rln_w = rlnw; s.rln_b = rlnb; s.rstats = rstats;
+        if (kvl) {
+            s.k_cache = kvl->k_self; s.v_cache = kvl->v_self; s.step = d->step;
+            s.E = E; s.H = H; s.dh = d->dh; s.dhp = d->dhp; s.Tmax = d->Tmax;
+        }
+        return launch_skinny<TW>(s, st);
+    };
+    if (fused) {
+        float *st0 = d->stats, *st1 = d->stats + 2 * B, *st2 = d->stats + 4 * B;
+        float *zin = d->x, *z1 = d->proj, *z2 = d->xn;
+        const float *lnw = nullptr, *lnb = nullptr;  // LayerNorm still to be applied to zin (norm3 of the previous layer)
+        for (int l = 0; l < d->L; ++l) {
+            const AcaiDecLayer *ly = d->layers + l;
+            if ((rc = skinny_ln(zin, E, ly->self_in_w, ly->self_in_b, d->qkv, 3 * E, 3 * E, E, rnd, ly, lnw, lnb, st0, nullptr, nullptr, nullptr, nullptr))) return rc;
+            if ((rc = attend(d->qkv, 3 * E, ly->k_self, ly->v_self, false))) return rc;
+            if ((rc = skinny_ln(d->attn, E, ly->self_out_w, ly->self_out_b, z1, E, E, E, rnd, nullptr, nullptr, nullptr, nullptr, zin, lnw, lnb, st0))) return rc;
+            if ((rc = skinny_ln(z1, E, ly->cross_q_w, ly->cross_q_b, d->qkv, 3 * E, E, E, rnd, nullptr, ly->n1_w, ly->n1_b, st1, nullptr, nullptr, nullptr, nullptr))) return rc;
+            if ((rc = attend(d->qkv, 3 * E, ly->k_cross, ly->v_cross, true))) return rc;
+            if ((rc = skinny_ln(d->attn, E, ly->cross_out_w, ly->cross_out_b, z2, E, E, E, rnd, nullptr, nullptr, nullptr, nullptr, z1, ly->n1_w, ly->n1_b, st1))) return rc;
+            if ((rc = skinny_ln(z2, E, ly->lin1_w, ly->lin1_b, d->hid, F, F, E, rnd | ACAI_GEMM_GELU, nullptr, ly->n2_w, ly->n2_b, st2, nullptr, nullptr, nullptr, nullptr))) return rc;
+            if ((rc = skinny_ln(d->hid, F, ly->lin2_w, ly->lin2_b, zin, E, E, F, rnd, nullptr, nullptr, nullptr, nullptr, z2, ly->n2_w, ly->n2_b, st2))) return rc;
+            lnw = ly->n3_w;
+            lnb = ly->n3_b;
+        }
+        // x = norm3(z3) of the last layer, then the stack's final norm (eps 1e-6) fused into the unembed GEMV
+        if ((rc = acai_layernorm_fwd(zin, lnw, lnb, 1e-5f, d->proj, nullptr, B, E, st))) return rc;
+        if (do_unembed && d->fn_w) {
+            SkinnyArgs s{};
+            s.x = d->proj; s.W = d->unembed_w; s.bias = d->unembed_b; s.y = d->logits;
+            s.ldx = E; s.ldw = E; s.ldy = d->V; s.B = B; s.N = d->V; s.K = E; s.flags = rnd;
+            s.ln_w = d->fn_w; s.ln_b = d->fn_b; s.ln_eps = 1e-6f;
+            return launch_skinny<TW>(s, st);
+        }
+        if (d->fn_w) {
+            if ((rc = acai_layernorm_fwd(d->proj, d->fn_w, d->fn_b, 1e-6f, d->xn, nullptr, B, E, st))) return rc;
+        } else {
+            hipError_t e = hipMemcpyAsync(d->xn, d->proj, sizeof(float) * (size_t)B * E, hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) return acai_set_err((int)e, "hipMemcpyAsync: %s", hipGetErrorString(e));
+        }
+    } else {
     for (int l = 0; l < d->L; ++l) {
         const AcaiDecLayer *ly = d->layers + l;
         // self attention (K:193-208)
@@ -451,6 +645,7 @@ int decode_core(const AcaiDecoder *d, const int64_t *tokens, hipStream_t st, boo
     } else {
         hipError_t e = hipMemcpyAsync(d->xn, d->x, sizeof(float) * (size_t)B * E, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return acai_set_err((int)e, "hipMemcpyAsync: %s", hipGetErrorString(e));
+    }
     }
     if (do_unembed) {
         SkinnyArgs s{};

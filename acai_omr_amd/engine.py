@@ -157,6 +157,7 @@ class DecodeEngine:
         self.cross_len = z(self.Bmax, dt=torch.int32)
         self.ws = dict(x=z(self.Bmax, self.E), xn=z(self.Bmax, self.E), qkv=z(self.Bmax, 3 * self.E), attn=z(self.Bmax, self.E),
                        proj=z(self.Bmax, self.E), hid=z(self.Bmax, self.F), logits=z(self.Bmax, self.V))
+        self.stats = z(6 * self.Bmax)
         self.self_nsplit = -(-self.Tmax // self.SELF_CHUNK)
         self.partial = None
         self.k_cross = self.v_cross = None
@@ -256,6 +257,7 @@ class DecodeEngine:
         for k, v in self.ws.items():
             setattr(d, k, P(v))
         d.partial = P(self.partial)
+        d.stats = P(self.stats)
         sig = tuple(getattr(layers[i], f) for i in range(self.L) for f, _ in _lib.AcaiDecLayer._fields_) + \
             tuple(getattr(d, f) for f, t in _lib.AcaiDecoder._fields_ if t is ctypes.c_void_p)
         if getattr(self, "_sig", None) != sig:

@@ -102,6 +102,7 @@ typedef struct {
     int32_t *step;                      /* device scalar t: next position to fill (starts at 1) */
     int32_t *finished;                  /* [B] flags + [B] = count of unfinished rows after the step */
     float *x, *xn, *qkv, *attn, *proj, *hid, *logits, *partial; /* workspaces, see DESIGN.md */
+    float *stats;                       /* 6*B floats: published LayerNorm (mean, rstd) rows; NULL disables the fused-LN path */
 } AcaiDecoder;
 
 /* One greedy step t = *step for all B rows: embed seqs[:,t-1] with pos_embedding[t] (quirk Q1, M:576),
