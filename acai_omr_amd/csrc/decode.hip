@@ -13,6 +13,8 @@
 //   decode_attn   : flash-decoding split over keys: grid (split, head, sequence), 8 lanes per key
 //                   (dh 64 bf16 = 128 B), online softmax per lane group, in-wave + LDS combine, one
 //                   (m, l, o[dh]) partial per workgroup; attn_combine merges the splits.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -37,6 +39,9 @@ struct SkinnyArgs {
     float ln_eps;
     float *stats_out;        // [B][2]
     const float *rln_w, *rln_b, *rstats;
+    int x_bf16, y_bf16;      // activation in / out stored as bf16 (x: row stride ldx in bf16 elements)
+    int rows_per_block;      // MFMA kernel: weight rows per workgroup (set by the launcher)
+    int ablate;              // diagnostics only (ACAI_SKINNY_ABLATE): 1 = no weight loads, 2 = no activation loads, 4 = no MFMA
 };
 
 template <typename TW, bool FAST>
@@ -131,96 +136,63 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
 
 // ---- bf16 weights: MFMA skinny GEMM ---------------------------------------------------------------------------
 // Workgroup = 16 weight rows x all of K; wave w owns K/4 of it, so every lane streams its 16-byte fragments of the
-// weight rows straight into VGPRs (8 loads in flight per lane) and v_mfma_f32_16x16x32_bf16 does the K reduction:
-// A = W[16 rows][32 k], B = x^T[32 k][16 batch columns] (activation rounded to bf16 on load = autocast's input cast),
-// D[row][batch] accumulates in fp32.  No cross-lane shuffles, no LDS staging of x; the 4 K-slices meet in LDS once.
-// Optional fusions remove the per-row LayerNorm launches of the decode step (post-LN: x = LN(z)): LN on load of the
-// activation, and LN of the residual from statistics a previous launch published.
-__global__ __launch_bounds__(256) void skinny_mfma_kernel(SkinnyArgs a) {
-    __shared__ float red[4][256];
-    __shared__ float stats[16][2];
+// weight rows straight into VGPRs (8 loads in flight per lane, issued BEFORE anything else) and
+// v_mfma_f32_16x16x32_bf16 does the K reduction: A = W[16 rows][32 k], B = x^T[32 k][16 batch columns], D[row][batch]
+// in fp32.  No cross-lane shuffles.  While the weight loads fly, the four waves build the bf16 activation image in
+// LDS (pitch K*2+16 bytes: conflict-free ds_read_b128 over 16 rows): each wave reads whole rows of x into registers
+// once, optionally applies the LayerNorm (post-LN decoder: x = LN(z)) from in-register statistics, rounds to bf16
+// (= autocast's input cast).  The 4 K-slices meet in LDS once.  Fusions that remove launches from the decode step:
+// LN on load, published (mean, rstd) for the residual path of a later launch, bf16 activations in / out.
+constexpr int SKM_MAXK = 4096;
+
+template <int NV>
+__device__ __forceinline__ void skm_row_stats(const float4 (&v)[NV], int K, int lane, float eps, float &mean, float &rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+        if (j * 256 + lane * 4 < K) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    mean = wave_sum(s) / (float)K;
+    float qq = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+        if (j * 256 + lane * 4 < K) {
+            const float d0 = v[j].x - mean, d1 = v[j].y - mean, d2 = v[j].z - mean, d3 = v[j].w - mean;
+            qq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    rstd = 1.0f / sqrtf(wave_sum(qq) / (float)K + eps);
+}
+
+// NV = float4 registers per lane for one fp32 activation row (K <= 256 * NV); NW = waves per workgroup = K slices
+// (NW = K/256 puts a slice's 8 weight fragments per lane in flight at once: one HBM round trip per workgroup)
+template <bool XBF16, int NV, int NW>
+__global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int n0 = blockIdx.x * 16;
-    const int Kw = a.K >> 2, kbase = wave * Kw, nch = Kw >> 5;
-    const bool row_ok = n0 + r < a.N;
+    const int R = a.rows_per_block;                            // weight rows of this workgroup (4, 8 or 16)
+    const int n0 = blockIdx.x * R;
+    const int K = a.K, Kw = K / NW, kbase = wave * Kw, nch = Kw >> 5;
+    const int pitch = K * 2 + 16;
+    const bool row_ok = r < R && n0 + r < a.N && !(a.ablate & 1);
     const bf16_t *Wrow = reinterpret_cast<const bf16_t *>(a.W) + (size_t)(row_ok ? n0 + r : 0) * a.ldw + kbase + 8 * q;
+    float *red = reinterpret_cast<float *>(smem);              // [NW][256] floats
+    unsigned char *xs = smem + NW * 1024;                      // [rows][pitch] bf16 activation image
 
     for (int bt = 0; bt < a.B; bt += 16) {
         const int nb = min(16, a.B - bt);
-        if (a.ln_w) {
-            __syncthreads();
-            for (int b = wave; b < nb; b += 4) {
-                const float *xr = a.x + (size_t)(bt + b) * a.ldx;
-                float s = 0.f;
-                for (int i = lane * 4; i < a.K; i += 256) {
-                    const float4 v = *reinterpret_cast<const float4 *>(xr + i);
-                    s += (v.x + v.y) + (v.z + v.w);
-                }
-                const float mean = wave_sum(s) / (float)a.K;
-                float qq = 0.f;
-                for (int i = lane * 4; i < a.K; i += 256) {
-                    const float4 v = *reinterpret_cast<const float4 *>(xr + i);
-                    const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-                    qq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-                }
-                const float rstd = 1.0f / sqrtf(wave_sum(qq) / (float)a.K + a.ln_eps);
-                if (lane == 0) {
-                    stats[b][0] = mean;
-                    stats[b][1] = rstd;
-                    if (a.stats_out && blockIdx.x == 0) {
-                        a.stats_out[(bt + b) * 2] = mean;
-                        a.stats_out[(bt + b) * 2 + 1] = rstd;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        const bool col_ok = r < nb;
-        const float *xrow = a.x + (size_t)(bt + (col_ok ? r : 0)) * a.ldx + kbase + 8 * q;
-        float mean = 0.f, rstd = 1.f;
-        if (a.ln_w && col_ok) {
-            mean = stats[r][0];
-            rstd = stats[r][1];
-        }
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int c0 = 0; c0 < nch; c0 += 8) {
-            uint4 wf[8];
+        // 1. first batch of weight fragments in flight
+        uint4 wf[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                wf[c] = make_uint4(0, 0, 0, 0);
-                if (c0 + c < nch && row_ok) wf[c] = *reinterpret_cast<const uint4 *>(Wrow + 32 * (c0 + c));
-            }
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                if (c0 + c < nch) {
-                    uint4 xf = make_uint4(0, 0, 0, 0);
-                    if (col_ok) {
-                        float4 x0 = *reinterpret_cast<const float4 *>(xrow + 32 * (c0 + c));
-                        float4 x1 = *reinterpret_cast<const float4 *>(xrow + 32 * (c0 + c) + 4);
-                        if (a.ln_w) {
-                            const int k = kbase + 8 * q + 32 * (c0 + c);
-                            const float4 w0 = *reinterpret_cast<const float4 *>(a.ln_w + k), w1 = *reinterpret_cast<const float4 *>(a.ln_w + k + 4);
-                            const float4 b0 = *reinterpret_cast<const float4 *>(a.ln_b + k), b1 = *reinterpret_cast<const float4 *>(a.ln_b + k + 4);
-                            x0.x = (x0.x - mean) * rstd * w0.x + b0.x; x0.y = (x0.y - mean) * rstd * w0.y + b0.y;
-                            x0.z = (x0.z - mean) * rstd * w0.z + b0.z; x0.w = (x0.w - mean) * rstd * w0.w + b0.w;
-                            x1.x = (x1.x - mean) * rstd * w1.x + b1.x; x1.y = (x1.y - mean) * rstd * w1.y + b1.y;
-                            x1.z = (x1.z - mean) * rstd * w1.z + b1.z; x1.w = (x1.w - mean) * rstd * w1.w + b1.w;
-                        }
-                        xf = make_uint4(pack_bf16(x0.x, x0.y), pack_bf16(x0.z, x0.w), pack_bf16(x1.x, x1.y), pack_bf16(x1.z, x1.w));
-                    }
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[c]), __builtin_bit_cast(bf16x8, xf), acc, 0, 0, 0);
-                }
-            }
+        for (int c = 0; c < 8; ++c) {
+            wf[c] = make_uint4(0, 0, 0, 0);
+            if (c < nch && row_ok) wf[c] = *reinterpret_cast<const uint4 *>(Wrow + 32 * c);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) red[wave][lane * 4 + i] = acc[i];
-        __syncthreads();
+        // 1b. wave 0 also fetches everything its epilogue needs now, so that nothing is loaded after the reduction
+        float e_bias[4] = {0.f, 0.f, 0.f, 0.f}, e_res[4] = {0.f, 0.f, 0.f, 0.f}, e_rw[4] = {1.f, 1.f, 1.f, 1.f}, e_rb[4] = {0.f, 0.f, 0.f, 0.f};
+        float rmean = 0.f, rrstd = 1.f;
         if (wave == 0) {
-            // D layout: col (batch) = lane & 15, row (weight row) = 4 * (lane >> 4) + i
             const int b = bt + r;
-            const bool rnd = a.flags & ACAI_GEMM_ROUND_BF16;
-            float rmean = 0.f, rrstd = 1.f;
+            const bool col_ok = r < nb;
             if (a.rln_w && col_ok) {
                 rmean = a.rstats[b * 2];
                 rrstd = a.rstats[b * 2 + 1];
@@ -228,9 +200,138 @@ __global__ __launch_bounds__(256) void skinny_mfma_kernel(SkinnyArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int n = n0 + 4 * q + i;
-                if (n >= a.N || !col_ok) continue;
-                float v = red[0][lane * 4 + i] + red[1][lane * 4 + i] + red[2][lane * 4 + i] + red[3][lane * 4 + i];
-                v += a.bias ? a.bias[n] : 0.f;
+                if (4 * q + i < R && n < a.N) {
+                    if (a.bias) e_bias[i] = a.bias[n];
+                    if (a.residual && col_ok) e_res[i] = a.residual[(size_t)b * a.ldr + n];
+                    if (a.rln_w) {
+                        e_rw[i] = a.rln_w[n];
+                        e_rb[i] = a.rln_b[n];
+                    }
+                }
+            }
+        }
+        // 2. activation image: wave w takes rows w, w+4 (together), then w+8, w+12; lane takes 4-element groups
+        if (a.ablate & 2) {
+        } else if constexpr (XBF16) {
+            // plain copy of the bf16 rows; every load of a row is issued before its first LDS store
+            for (int b0 = wave; b0 < nb; b0 += NW) {
+                const bf16_t *xr0 = reinterpret_cast<const bf16_t *>(a.x) + (size_t)(bt + b0) * a.ldx;
+                uint4 t0[SKM_MAXK / 512];
+#pragma unroll
+                for (int j = 0; j < SKM_MAXK / 512; ++j)
+                    if (j * 512 + lane * 8 < K) t0[j] = *reinterpret_cast<const uint4 *>(xr0 + j * 512 + lane * 8);
+#pragma unroll
+                for (int j = 0; j < SKM_MAXK / 512; ++j)
+                    if (j * 512 + lane * 8 < K) *reinterpret_cast<uint4 *>(xs + b0 * pitch + (j * 512 + lane * 8) * 2) = t0[j];
+            }
+        } else if constexpr (NV <= 4) {
+            for (int b0 = wave; b0 < nb; b0 += 2 * NW) {
+                const bool two = b0 + NW < nb;
+                const float *xr0 = a.x + (size_t)(bt + b0) * a.ldx, *xr1 = a.x + (size_t)(bt + (two ? b0 + NW : b0)) * a.ldx;
+                float4 v0[NV], v1[NV], lw[NV], lb[NV];
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+                    if (j * 256 + lane * 4 < K) {
+                        v0[j] = *reinterpret_cast<const float4 *>(xr0 + j * 256 + lane * 4);
+                        v1[j] = *reinterpret_cast<const float4 *>(xr1 + j * 256 + lane * 4);
+                        if (a.ln_w) {
+                            lw[j] = *reinterpret_cast<const float4 *>(a.ln_w + j * 256 + lane * 4);
+                            lb[j] = *reinterpret_cast<const float4 *>(a.ln_b + j * 256 + lane * 4);
+                        }
+                    }
+                if (a.ln_w) {
+                    float m0, s0, m1, s1;
+                    skm_row_stats<NV>(v0, K, lane, a.ln_eps, m0, s0);
+                    skm_row_stats<NV>(v1, K, lane, a.ln_eps, m1, s1);
+                    if (lane == 0 && a.stats_out && blockIdx.x == 0) {
+                        a.stats_out[(bt + b0) * 2] = m0;
+                        a.stats_out[(bt + b0) * 2 + 1] = s0;
+                        if (two) {
+                            a.stats_out[(bt + b0 + NW) * 2] = m1;
+                            a.stats_out[(bt + b0 + NW) * 2 + 1] = s1;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < NV; ++j)
+                        if (j * 256 + lane * 4 < K) {
+                            v0[j].x = (v0[j].x - m0) * s0 * lw[j].x + lb[j].x; v0[j].y = (v0[j].y - m0) * s0 * lw[j].y + lb[j].y;
+                            v0[j].z = (v0[j].z - m0) * s0 * lw[j].z + lb[j].z; v0[j].w = (v0[j].w - m0) * s0 * lw[j].w + lb[j].w;
+                            v1[j].x = (v1[j].x - m1) * s1 * lw[j].x + lb[j].x; v1[j].y = (v1[j].y - m1) * s1 * lw[j].y + lb[j].y;
+                            v1[j].z = (v1[j].z - m1) * s1 * lw[j].z + lb[j].z; v1[j].w = (v1[j].w - m1) * s1 * lw[j].w + lb[j].w;
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+                    if (j * 256 + lane * 4 < K) {
+                        const int kb = (j * 256 + lane * 4) * 2;
+                        *reinterpret_cast<uint2 *>(xs + b0 * pitch + kb) = make_uint2(pack_bf16(v0[j].x, v0[j].y), pack_bf16(v0[j].z, v0[j].w));
+                        if (two) *reinterpret_cast<uint2 *>(xs + (b0 + NW) * pitch + kb) = make_uint2(pack_bf16(v1[j].x, v1[j].y), pack_bf16(v1[j].z, v1[j].w));
+                    }
+            }
+        } else {
+            for (int b = wave; b < nb; b += NW) {
+                const float *xr = a.x + (size_t)(bt + b) * a.ldx;
+                float4 v[NV];
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+                    if (j * 256 + lane * 4 < K) v[j] = *reinterpret_cast<const float4 *>(xr + j * 256 + lane * 4);
+                float mean = 0.f, rstd = 1.f;
+                if (a.ln_w) {
+                    skm_row_stats<NV>(v, K, lane, a.ln_eps, mean, rstd);
+                    if (lane == 0 && a.stats_out && blockIdx.x == 0) {
+                        a.stats_out[(bt + b) * 2] = mean;
+                        a.stats_out[(bt + b) * 2 + 1] = rstd;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+                    if (j * 256 + lane * 4 < K) {
+                        const int k = j * 256 + lane * 4;
+                        if (a.ln_w) {
+                            const float4 w4 = *reinterpret_cast<const float4 *>(a.ln_w + k), b4 = *reinterpret_cast<const float4 *>(a.ln_b + k);
+                            v[j].x = (v[j].x - mean) * rstd * w4.x + b4.x; v[j].y = (v[j].y - mean) * rstd * w4.y + b4.y;
+                            v[j].z = (v[j].z - mean) * rstd * w4.z + b4.z; v[j].w = (v[j].w - mean) * rstd * w4.w + b4.w;
+                        }
+                        *reinterpret_cast<uint2 *>(xs + b * pitch + k * 2) = make_uint2(pack_bf16(v[j].x, v[j].y), pack_bf16(v[j].z, v[j].w));
+                    }
+            }
+        }
+        __syncthreads();
+        // 3. MFMA over this wave's K slice; batch columns >= nb read row 0 (their outputs are never stored)
+        const unsigned char *xfrag = xs + (r < nb ? r : 0) * pitch + (kbase + 8 * q) * 2;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < nch; c0 += 8) {
+            uint4 wn[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {  // next batch of weight fragments (none when NW covers K in one batch)
+                wn[c] = make_uint4(0, 0, 0, 0);
+                if constexpr (NW * 256 < SKM_MAXK)
+                    if (c0 + 8 + c < nch && row_ok) wn[c] = *reinterpret_cast<const uint4 *>(Wrow + 32 * (c0 + 8 + c));
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c0 + c < nch && !(a.ablate & 4)) {
+                    const uint4 xf = *reinterpret_cast<const uint4 *>(xfrag + 64 * (c0 + c));
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[c]), __builtin_bit_cast(bf16x8, xf), acc, 0, 0, 0);
+                }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) wf[c] = wn[c];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave * 256 + lane * 4 + i] = acc[i];
+        __syncthreads();
+        if (wave == 0) {
+            // D layout: col (batch) = lane & 15, row (weight row) = 4 * (lane >> 4) + i
+            const int b = bt + r;
+            const bool col_ok = r < nb;
+            const bool rnd = a.flags & ACAI_GEMM_ROUND_BF16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + 4 * q + i;
+                if (4 * q + i >= R || n >= a.N || !col_ok) continue;
+                float v = e_bias[i];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) v += red[w * 256 + lane * 4 + i];
                 if (rnd) v = round_bf16(v);
                 if (a.flags & ACAI_GEMM_GELU) {
                     v = gelu_erf(v);
@@ -241,12 +342,11 @@ __global__ __launch_bounds__(256) void skinny_mfma_kernel(SkinnyArgs a) {
                     const size_t off = (((size_t)b * a.H + hh) * a.Tmax + a.step[1]) * a.dhp + dd;
                     reinterpret_cast<bf16_t *>(kv ? a.v_cache : a.k_cache)[off] = f2bf(v);
                 }
-                if (a.residual) {
-                    float rv = a.residual[(size_t)b * a.ldr + n];
-                    if (a.rln_w) rv = (rv - rmean) * rrstd * a.rln_w[n] + a.rln_b[n];
-                    v += rv;
-                }
-                a.y[(size_t)b * a.ldy + n] = v;
+                if (a.residual) v += a.rln_w ? (e_res[i] - rmean) * rrstd * e_rw[i] + e_rb[i] : e_res[i];
+                if (a.y_bf16)
+                    reinterpret_cast<bf16_t *>(a.y)[(size_t)b * a.ldy + n] = f2bf(v);
+                else
+                    a.y[(size_t)b * a.ldy + n] = v;
             }
         }
         __syncthreads();
@@ -254,7 +354,7 @@ __global__ __launch_bounds__(256) void skinny_mfma_kernel(SkinnyArgs a) {
 }
 
 static inline bool skinny_mfma_ok(const SkinnyArgs &a) {
-    return (a.K % 128 == 0) && (a.ldw % 8 == 0) && (a.ldx % 4 == 0) && aligned16(a.W) && aligned16(a.x) &&
+    return (a.K % 256 == 0) && a.K <= SKM_MAXK && (a.ldw % 8 == 0) && (a.ldx % 8 == 0) && aligned16(a.W) && aligned16(a.x) &&
            (!a.ln_w || (aligned16(a.ln_w) && aligned16(a.ln_b)));
 }
 
@@ -262,12 +362,38 @@ template <typename TW>
 int launch_skinny(const SkinnyArgs &a, hipStream_t st) {
     if constexpr (sizeof(TW) == 2) {
         if (skinny_mfma_ok(a)) {
-            hipLaunchKernelGGL(skinny_mfma_kernel, dim3(cdiv(a.N, 16)), dim3(256), 0, st, a);
+            const int rows = a.B < 16 ? ((a.B + 3) & ~3) : 16;
+            const bool wide = a.x_bf16 && a.K == 4096;  // 16 K-slices: every weight fragment of the workgroup in flight at once
+            const size_t lds = (wide ? 16 : 4) * 1024 + (size_t)rows * (a.K * 2 + 16);
+            static bool attr_done = false;
+            if (!attr_done) {  // opt in to > 64 KB of dynamic LDS (K = 4096 activation image)
+                hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_mfma_kernel<false, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+                hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_mfma_kernel<false, 16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+                hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_mfma_kernel<true, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+                hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_mfma_kernel<true, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+                attr_done = true;
+            }
+            // one CU ingests only ~25 GB/s from HBM: spread a small weight matrix over >= ~200 workgroups by giving each
+            // fewer than 16 rows (the unused MFMA rows load nothing)
+            SkinnyArgs b = a;
+            static const int abl = getenv("ACAI_SKINNY_ABLATE") ? atoi(getenv("ACAI_SKINNY_ABLATE")) : 0;
+            static const int rpb = getenv("ACAI_SKINNY_ROWS") ? atoi(getenv("ACAI_SKINNY_ROWS")) : 0;
+            b.ablate = abl;
+            b.rows_per_block = rpb ? rpb : (a.N >= 3200 ? 16 : (a.N >= 1600 ? 8 : 4));
+            const dim3 grid(cdiv(a.N, b.rows_per_block));
+            if (wide)
+                hipLaunchKernelGGL((skinny_mfma_kernel<true, 1, 16>), grid, dim3(1024), lds, st, b);
+            else if (a.x_bf16)
+                hipLaunchKernelGGL((skinny_mfma_kernel<true, 1, 4>), grid, dim3(256), lds, st, b);
+            else if (a.K <= 1024)
+                hipLaunchKernelGGL((skinny_mfma_kernel<false, 4, 4>), grid, dim3(256), lds, st, b);
+            else
+                hipLaunchKernelGGL((skinny_mfma_kernel<false, 16, 4>), grid, dim3(256), lds, st, b);
             ACAI_LAUNCH_CHECK("skinny_mfma");
             return 0;
         }
     }
-    if (a.ln_w || a.rln_w) return acai_set_err(-1, "skinny_gemm: fused LayerNorm needs the bf16 MFMA path (K %% 128 == 0, 16-byte aligned operands)");
+    if (a.ln_w || a.rln_w || a.x_bf16 || a.y_bf16) return acai_set_err(-1, "skinny_gemm: fused LayerNorm needs the bf16 MFMA path (K %% 128 == 0, 16-byte aligned operands)");
     constexpr int EPC = 16 / sizeof(TW);
     const bool fast = (a.K % EPC == 0) && (a.ldw % EPC == 0) && aligned16(a.W);
     dim3 grid(cdiv(a.N, 32));
@@ -289,6 +415,8 @@ struct DAttnArgs {
     float *partial;          // [B][H][nsplit][dhp + 2]
     int ldq, H, dh, dhp, Tmax, chunk, nsplit;
     float scale_log2e;
+    float *out;              // nsplit == 1: the workgroup writes softmax(qK^T)V itself to out[b, h*dh + d] (no combine launch)
+    int ldo, round_out;
 };
 
 // LPK = lanes per key = dhp * sizeof(TC) / 16.  RAGGED = cross attention over the ragged encoder memory (the dominant
@@ -403,13 +531,22 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DAttnArgs a) {
     __syncthreads();
     if (tid < a.dhp + 2) {
         const float M = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
-        if (tid == 0) {
-            part[0] = M;
-        } else {
-            float v = 0.f;
+        float v = 0.f, lsum = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v += red[w][tid] * exp2f(red[w][0] - M);
-            part[tid] = v;
+        for (int w = 0; w < 4; ++w) {
+            const float f = exp2f(red[w][0] - M);
+            v += red[w][tid] * f;
+            lsum += red[w][1] * f;
+        }
+        if (a.nsplit == 1 && a.out) {
+            const int d = tid - 2;
+            if (d >= 0 && d < a.dh) {
+                float o = v / lsum;
+                if (a.round_out) o = round_bf16(o);
+                a.out[(size_t)b * a.ldo + h * a.dh + d] = o;
+            }
+        } else {
+            part[tid] = tid == 0 ? M : v;
         }
     }
 }
@@ -565,6 +702,10 @@ int decode_core(const AcaiDecoder *d, const int64_t *tokens, hipStream_t st, boo
         } else {
             a.step = d->step; a.chunk = d->self_chunk; a.nsplit = d->self_nsplit;
         }
+        if (a.nsplit == 1) {
+            a.out = d->attn; a.ldo = E; a.round_out = rnd ? 1 : 0;
+            return launch_dattn<TW>(a, B, st);
+        }
         int r = launch_dattn<TW>(a, B, st);
         if (r) return r;
         hipLaunchKernelGGL(attn_combine_kernel, dim3(H, B), dim3(64), 0, st, d->partial, d->attn, E, H, d->dh, d->dhp, a.nsplit, rnd ? 1 : 0);
@@ -576,7 +717,8 @@ int decode_core(const AcaiDecoder *d, const int64_t *tokens, hipStream_t st, boo
     // LayerNorm on load, so a layer is 6 GEMV + 2 attention (+2 combine) launches instead of 17.
     SkinnyArgs probe{};
     probe.x = d->x; probe.W = d->layers[0].self_in_w; probe.K = E; probe.ldw = E; probe.ldx = E;
-    const bool fused = sizeof(TW) == 2 && d->stats && skinny_mfma_ok(probe) && (F % 128 == 0);
+    const bool fused = sizeof(TW) == 2 && d->stats && rnd && skinny_mfma_ok(probe) && (F % 256 == 0) && F <= SKM_MAXK;
+    bool hid_bf16 = false, hid_in_bf16 = false;
     auto skinny_ln = [&](const float *x, int ldx, const void *W, const float *bias, float *y, int ldy, int N, int K, int flags,
                          const AcaiDecLayer *kvl, const float *lnw, const float *lnb, float *stats_out, const float *res,
                          const float *rlnw, const float *rlnb, const float *rstats) -> int {
@@ -584,6 +726,8 @@ int decode_core(const AcaiDecoder *d, const int64_t *tokens, hipStream_t st, boo
         s.x = x; s.W = W; s.bias = bias; s.residual = res; s.y = y;
         s.ldx = ldx; s.ldw = K; s.ldr = E; s.ldy = ldy; s.B = B; s.N = N; s.K = K; s.flags = flags;
         s.ln_w = lnw; s.ln_b = lnb; s.ln_eps = 1e-5f; s.stats_out = stats_out; s.rln_w = rlnw; s.rln_b = rlnb; s.rstats = rstats;
+        s.y_bf16 = hid_bf16 && (flags & ACAI_GEMM_ROUND_BF16);
+        s.x_bf16 = hid_in_bf16 && (flags & ACAI_GEMM_ROUND_BF16);
         if (kvl) {
             s.k_cache = kvl->k_self; s.v_cache = kvl->v_self; s.step = d->step;
             s.E = E; s.H = H; s.dh = d->dh; s.dhp = d->dhp; s.Tmax = d->Tmax;
@@ -602,8 +746,12 @@ int decode_core(const AcaiDecoder *d, const int64_t *tokens, hipStream_t st, boo
             if ((rc = skinny_ln(z1, E, ly->cross_q_w, ly->cross_q_b, d->qkv, 3 * E, E, E, rnd, nullptr, ly->n1_w, ly->n1_b, st1, nullptr, nullptr, nullptr, nullptr))) return rc;
             if ((rc = attend(d->qkv, 3 * E, ly->k_cross, ly->v_cross, true))) return rc;
             if ((rc = skinny_ln(d->attn, E, ly->cross_out_w, ly->cross_out_b, z2, E, E, E, rnd, nullptr, nullptr, nullptr, nullptr, z1, ly->n1_w, ly->n1_b, st1))) return rc;
+            hid_bf16 = true;   // linear1 -> GELU output is bf16 under autocast anyway: store it as such (half the x bytes of linear2)
             if ((rc = skinny_ln(z2, E, ly->lin1_w, ly->lin1_b, d->hid, F, F, E, rnd | ACAI_GEMM_GELU, nullptr, ly->n2_w, ly->n2_b, st2, nullptr, nullptr, nullptr, nullptr))) return rc;
+            hid_bf16 = false;
+            hid_in_bf16 = true;
             if ((rc = skinny_ln(d->hid, F, ly->lin2_w, ly->lin2_b, zin, E, E, F, rnd, nullptr, nullptr, nullptr, nullptr, z2, ly->n2_w, ly->n2_b, st2))) return rc;
+            hid_in_bf16 = false;
             lnw = ly->n3_w;
             lnb = ly->n3_b;
         }
@@ -669,6 +817,24 @@ extern "C" int acai_skinny_gemm(const float *x, int ldx, const void *W, int ldw,
     if (dtype == ACAI_BF16) return launch_skinny<bf16_t>(s, (hipStream_t)stream);
     if (dtype == ACAI_F32) return launch_skinny<float>(s, (hipStream_t)stream);
     return acai_set_err(-1, "acai_skinny_gemm: bad dtype %d", dtype);
+}
+
+// The full option set of the decode GEMV (what acai_decode_step chains): LayerNorm on load, published row statistics,
+// LayerNorm of the residual, bf16 activations in / out.  Exposed so that tests and micro-benchmarks can hit each fusion.
+extern "C" int acai_skinny_gemm_ex(const void *x, int ldx, int x_dtype, const void *W, int ldw, const float *bias, const float *residual,
+                                   int ldr, void *y, int ldy, int y_dtype, int B, int N, int K, int dtype, int flags, const float *ln_w,
+                                   const float *ln_b, float ln_eps, float *stats_out, const float *rln_w, const float *rln_b,
+                                   const float *rstats, void *stream) {
+    ACAI_CHECK_ARG(x && W && y && B > 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && ldy >= N, "acai_skinny_gemm_ex: bad arguments");
+    ACAI_CHECK_ARG(!rln_w || (rln_b && rstats && residual), "acai_skinny_gemm_ex: residual LayerNorm needs weights, bias, statistics and a residual");
+    SkinnyArgs s{};
+    s.x = (const float *)x; s.W = W; s.bias = bias; s.residual = residual; s.y = (float *)y;
+    s.ldx = ldx; s.ldw = ldw; s.ldr = ldr; s.ldy = ldy; s.B = B; s.N = N; s.K = K; s.flags = flags;
+    s.ln_w = ln_w; s.ln_b = ln_b; s.ln_eps = ln_eps; s.stats_out = stats_out; s.rln_w = rln_w; s.rln_b = rln_b; s.rstats = rstats;
+    s.x_bf16 = x_dtype == ACAI_BF16; s.y_bf16 = y_dtype == ACAI_BF16;
+    if (dtype == ACAI_BF16) return launch_skinny<bf16_t>(s, (hipStream_t)stream);
+    if (dtype == ACAI_F32) return launch_skinny<float>(s, (hipStream_t)stream);
+    return acai_set_err(-1, "acai_skinny_gemm_ex: bad dtype %d", dtype);
 }
 
 extern "C" int acai_decode_attn(const float *q, int ldq, const void *kc, const void *vc, const int64_t *seq_off, const int32_t *seq_len,

@@ -123,8 +123,7 @@ def unpad_rows(padded, mask):
 class DecodeEngine:
     """Owns the KV caches, workspaces and hipGraphs of one CachedTransformerDecoder-equivalent."""
 
-    SELF_CHUNK = 256
-    CROSS_CHUNK = 512
+    CROSS_CHUNK = 512   # keys per cross-attention workgroup (split over the memory, merged by attn_combine)
 
     def __init__(self, blocks, omr, max_batch_size, max_len, prec, device):
         self.blocks = blocks        # CachedTransformerDecoder mirror (layers, norm): parameters are read from it
@@ -158,7 +157,10 @@ class DecodeEngine:
         self.ws = dict(x=z(self.Bmax, self.E), xn=z(self.Bmax, self.E), qkv=z(self.Bmax, 3 * self.E), attn=z(self.Bmax, self.E),
                        proj=z(self.Bmax, self.E), hid=z(self.Bmax, self.F), logits=z(self.Bmax, self.V))
         self.stats = z(6 * self.Bmax)
-        self.self_nsplit = -(-self.Tmax // self.SELF_CHUNK)
+        # self-attention: one workgroup per (sequence, head) walks the whole cache (t <= 1536 keys) and writes the output
+        # itself - no split, no combine launch
+        self.SELF_CHUNK = self.Tmax
+        self.self_nsplit = 1
         self.partial = None
         self.k_cross = self.v_cross = None
         self.cross_cap = 0

@@ -143,6 +143,22 @@ def skinny_gemm(x, w, bias=None, residual=None, gelu=False, round_bf16=False, ou
     return out
 
 
+def skinny_gemm_ex(x, w, bias=None, residual=None, gelu=False, round_bf16=False, out_dtype=torch.float32, ln=None, stats_out=None,
+                   rln=None, rstats=None, ln_eps=1e-5):
+    """Decode GEMV with its fusions: x [B,K] fp32 or bf16, w [N,K]; ln = (weight, bias) applied to x on load;
+    rln = (weight, bias) + rstats [B,2] applied to the residual."""
+    _chk(x, "x"), _chk(w, "w")
+    B, K = x.shape
+    N = w.shape[0]
+    out = torch.empty(B, N, dtype=out_dtype, device=x.device)
+    flags = (GEMM_GELU if gelu else 0) | (GEMM_ROUND_BF16 if round_bf16 else 0)
+    _lib.check(_lib.lib().acai_skinny_gemm_ex(x.data_ptr(), x.stride(0), _dt(x), w.data_ptr(), w.stride(0), _p(bias), _p(residual),
+                                              residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0), _dt(out), B, N, K,
+                                              _dt(w), flags, _p(ln[0]) if ln else None, _p(ln[1]) if ln else None, float(ln_eps), _p(stats_out),
+                                              _p(rln[0]) if rln else None, _p(rln[1]) if rln else None, _p(rstats), _st()), "acai_skinny_gemm_ex")
+    return out
+
+
 def decode_attn(q, kc, vc, seq_off, seq_len, H, dh, dhp, max_len, round_out=False, chunk=256):
     """q [B, H*dh] fp32 (row stride free); kc/vc flat caches addressed by seq_off / seq_len (see header)."""
     _chk(q, "q", torch.float32)

@@ -121,6 +121,13 @@ int acai_decode_hidden(const AcaiDecoder *dec, const float *x_in, void *stream);
 int acai_skinny_gemm(const float *x, int ldx, const void *W, int ldw, const float *bias, const float *residual, int ldr,
                      float *y, int ldy, int B, int N, int K, int dtype, int flags, void *stream);
 
+/* acai_skinny_gemm with the fusions the decode step uses (bf16 weights, K % 256 == 0): x may be bf16 (x_dtype), y may be bf16;
+ * ln_w/ln_b: x := LayerNorm(x) on load (norm1/2/3 of the post-LN layer, K:208,220,222), its per-row (mean, rstd) optionally
+ * published to stats_out[B][2]; rln_w/rln_b/rstats: residual := LayerNorm(residual) from published statistics. */
+int acai_skinny_gemm_ex(const void *x, int ldx, int x_dtype, const void *W, int ldw, const float *bias, const float *residual, int ldr,
+                        void *y, int ldy, int y_dtype, int B, int N, int K, int dtype, int flags, const float *ln_w, const float *ln_b,
+                        float ln_eps, float *stats_out, const float *rln_w, const float *rln_b, const float *rstats, void *stream);
+
 /* CachedMultiheadAttention.cached_forward's SDPA (K:131-136) for one query per sequence:
  * keys/values of sequence b, head h at kc/vc + seq_off[b] + (h*seq_len[b] + s)*dhp; out[b, h*dh + d] fp32.
  * partial: workspace of B*H*nsplit*(dhp+2) floats; chunk*nsplit must cover max(seq_len).
