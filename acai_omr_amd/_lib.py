@@ -30,7 +30,7 @@ class AcaiDecoder(Structure):
         "self_chunk", "cross_chunk", "self_nsplit", "cross_nsplit", "bos", "pad", "eos", "reserved")] + [
         ("layers", POINTER(AcaiDecLayer))] + [(n, c_void_p) for n in (
             "emb", "pos", "fn_w", "fn_b", "unembed_w", "unembed_b", "cross_off", "cross_len", "seqs", "logprobs",
-            "step", "finished", "x", "xn", "qkv", "attn", "proj", "hid", "logits", "partial", "stats")]
+            "step", "finished", "x", "xn", "qkv", "attn", "proj", "hid", "logits", "partial", "tickets", "stats")]
 
 
 _SIGNATURES = {
@@ -51,7 +51,7 @@ _SIGNATURES = {
     "acai_skinny_gemm_ex": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                     c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "acai_decode_attn": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                 c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+                                 c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "acai_decode_step": (c_int, [POINTER(AcaiDecoder), c_void_p]),
     "acai_decode_logits": (c_int, [POINTER(AcaiDecoder), c_void_p, c_int, c_void_p]),
     "acai_decode_hidden": (c_int, [POINTER(AcaiDecoder), c_void_p, c_void_p]),

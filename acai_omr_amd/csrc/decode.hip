@@ -417,6 +417,7 @@ struct DAttnArgs {
     float scale_log2e;
     float *out;              // nsplit == 1: the workgroup writes softmax(qK^T)V itself to out[b, h*dh + d] (no combine launch)
     int ldo, round_out;
+    unsigned *tickets;       // [B*H] arrival counters (zero between launches): the LAST workgroup of a (b, h) merges the splits
 };
 
 // LPK = lanes per key = dhp * sizeof(TC) / 16.  RAGGED = cross attention over the ragged encoder memory (the dominant
@@ -442,9 +443,13 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DAttnArgs a) {
     }
     float *part = a.partial + (((size_t)b * a.H + h) * a.nsplit + split) * (a.dhp + 2);
     const int c0 = split * a.chunk, c1 = min(len, c0 + a.chunk);
+    const bool fused_merge = a.tickets && a.out && a.nsplit > 1;
     if (c0 >= len) {  // empty split: neutral element
-        if (tid < a.dhp + 2) part[tid] = tid == 0 ? -1.0e30f : 0.f;
-        return;
+        if (tid < a.dhp + 2) {
+            if (fused_merge) __hip_atomic_store(part + tid, tid == 0 ? -1.0e30f : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else part[tid] = tid == 0 ? -1.0e30f : 0.f;
+        }
+        if (!fused_merge) return;
     }
     const TC *Kp = reinterpret_cast<const TC *>(a.kc) + base;
     const TC *Vp = reinterpret_cast<const TC *>(a.vc) + base;
@@ -545,8 +550,44 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DAttnArgs a) {
                 if (a.round_out) o = round_bf16(o);
                 a.out[(size_t)b * a.ldo + h * a.dh + d] = o;
             }
-        } else {
-            part[tid] = tid == 0 ? M : v;
+        } else if (c0 < len) {
+            // fused merge: write-through (sc1) stores, so the hand-off needs no release fence (an L2 write-back per workgroup)
+            if (fused_merge) __hip_atomic_store(part + tid, tid == 0 ? M : v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else part[tid] = tid == 0 ? M : v;
+        }
+    }
+    if (fused_merge) {
+        // In-launch merge of the split partials (placement-independent hand-off, write-through form): the partials were
+        // stored sc1 (agent-scope atomic stores), every storing wave drains its stores, the workgroup meets, ONE lane takes
+        // a ticket with an agent-scope atomic add; the workgroup that draws nsplit-1 reads every partial with sc1 loads
+        // (agent-scope atomic loads bypass this CU's L1) after a workgroup barrier and merges.  The counter re-arms itself.
+        __shared__ int s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            unsigned *cnt = a.tickets + (size_t)b * a.H + h;
+            const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = t == (unsigned)(a.nsplit - 1);
+            if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = last;
+        }
+        __syncthreads();
+        if (s_last && tid < a.dhp) {
+            float *p = a.partial + ((size_t)b * a.H + h) * a.nsplit * (a.dhp + 2);
+            auto ld = [&](int i) { return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            float M = -1.0e30f;
+            for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, ld(s * (a.dhp + 2)));
+            float l = 0.f, o = 0.f;
+            for (int s = 0; s < a.nsplit; ++s) {
+                const float w = exp2f(ld(s * (a.dhp + 2)) - M);
+                l += ld(s * (a.dhp + 2) + 1) * w;
+                o += ld(s * (a.dhp + 2) + 2 + tid) * w;
+            }
+            if (tid < a.dh) {
+                float v = o / l;
+                if (a.round_out) v = round_bf16(v);
+                a.out[(size_t)b * a.ldo + h * a.dh + tid] = v;
+            }
         }
     }
 }
@@ -706,6 +747,10 @@ int decode_core(const AcaiDecoder *d, const int64_t *tokens, hipStream_t st, boo
             a.out = d->attn; a.ldo = E; a.round_out = rnd ? 1 : 0;
             return launch_dattn<TW>(a, B, st);
         }
+        if (d->tickets) {
+            a.out = d->attn; a.ldo = E; a.round_out = rnd ? 1 : 0; a.tickets = d->tickets;
+            return launch_dattn<TW>(a, B, st);
+        }
         int r = launch_dattn<TW>(a, B, st);
         if (r) return r;
         hipLaunchKernelGGL(attn_combine_kernel, dim3(H, B), dim3(64), 0, st, d->partial, d->attn, E, H, d->dh, d->dhp, a.nsplit, rnd ? 1 : 0);
@@ -839,7 +884,7 @@ extern "C" int acai_skinny_gemm_ex(const void *x, int ldx, int x_dtype, const vo
 
 extern "C" int acai_decode_attn(const float *q, int ldq, const void *kc, const void *vc, const int64_t *seq_off, const int32_t *seq_len,
                                 float *partial, float *out, int ldo, int B, int H, int dh, int dhp, int chunk, int nsplit, int dtype,
-                                int round_out, void *stream) {
+                                int round_out, uint32_t *tickets, void *stream) {
     ACAI_CHECK_ARG(q && kc && vc && seq_off && seq_len && partial, "acai_decode_attn: null operand");
     ACAI_CHECK_ARG(B > 0 && H > 0 && dh > 0 && dhp >= dh && dhp <= 64 && (dhp & (dhp - 1)) == 0 && chunk > 0 && nsplit > 0,
                    "acai_decode_attn: bad dims");
@@ -848,6 +893,10 @@ extern "C" int acai_decode_attn(const float *q, int ldq, const void *kc, const v
     a.ldq = ldq; a.H = H; a.dh = dh; a.dhp = dhp; a.chunk = chunk; a.nsplit = nsplit;
     a.scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
     hipStream_t st = (hipStream_t)stream;
+    if (tickets && out) {
+        a.out = out; a.ldo = ldo; a.round_out = round_out; a.tickets = tickets;
+        return dtype == ACAI_BF16 ? launch_dattn<bf16_t>(a, B, st) : launch_dattn<float>(a, B, st);
+    }
     int rc = dtype == ACAI_BF16 ? launch_dattn<bf16_t>(a, B, st) : launch_dattn<float>(a, B, st);
     if (rc || !out) return rc;  // out == NULL: partials only (lets a benchmark time the streaming kernel alone)
     hipLaunchKernelGGL(attn_combine_kernel, dim3(H, B), dim3(64), 0, st, partial, out, ldo, H, dh, dhp, nsplit, round_out);

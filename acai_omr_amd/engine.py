@@ -157,6 +157,7 @@ class DecodeEngine:
         self.ws = dict(x=z(self.Bmax, self.E), xn=z(self.Bmax, self.E), qkv=z(self.Bmax, 3 * self.E), attn=z(self.Bmax, self.E),
                        proj=z(self.Bmax, self.E), hid=z(self.Bmax, self.F), logits=z(self.Bmax, self.V))
         self.stats = z(6 * self.Bmax)
+        self.tickets = z(self.Bmax * self.H, dt=torch.int32)   # self-resetting arrival counters (in-launch split merge)
         # self-attention: one workgroup per (sequence, head) walks the whole cache (t <= 1536 keys) and writes the output
         # itself - no split, no combine launch
         self.SELF_CHUNK = self.Tmax
@@ -260,6 +261,7 @@ class DecodeEngine:
             setattr(d, k, P(v))
         d.partial = P(self.partial)
         d.stats = P(self.stats)
+        d.tickets = P(self.tickets)
         sig = tuple(getattr(layers[i], f) for i in range(self.L) for f, _ in _lib.AcaiDecLayer._fields_) + \
             tuple(getattr(d, f) for f, t in _lib.AcaiDecoder._fields_ if t is ctypes.c_void_p)
         if getattr(self, "_sig", None) != sig:

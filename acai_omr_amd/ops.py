@@ -159,16 +159,19 @@ def skinny_gemm_ex(x, w, bias=None, residual=None, gelu=False, round_bf16=False,
     return out
 
 
-def decode_attn(q, kc, vc, seq_off, seq_len, H, dh, dhp, max_len, round_out=False, chunk=256):
+def decode_attn(q, kc, vc, seq_off, seq_len, H, dh, dhp, max_len, round_out=False, chunk=256, fused_merge=False):
     """q [B, H*dh] fp32 (row stride free); kc/vc flat caches addressed by seq_off / seq_len (see header)."""
     _chk(q, "q", torch.float32)
     B = q.shape[0]
     nsplit = max(1, -(-int(max_len) // chunk))
     partial = torch.empty(B * H * nsplit * (dhp + 2), dtype=torch.float32, device=q.device)
     out = torch.empty(B, H * dh, dtype=torch.float32, device=q.device)
+    tickets = torch.zeros(B * H, dtype=torch.int32, device=q.device) if fused_merge else None
     _lib.check(_lib.lib().acai_decode_attn(q.data_ptr(), q.stride(0), kc.data_ptr(), vc.data_ptr(), seq_off.data_ptr(), seq_len.data_ptr(),
                                            partial.data_ptr(), out.data_ptr(), out.stride(0), B, H, dh, dhp, chunk, nsplit, _dt(kc),
-                                           1 if round_out else 0, _st()), "acai_decode_attn")
+                                           1 if round_out else 0, tickets.data_ptr() if tickets is not None else None, _st()), "acai_decode_attn")
+    if tickets is not None:
+        assert int(tickets.abs().sum().item()) == 0, "arrival counters must re-arm to zero"
     return out
 
 

@@ -43,7 +43,7 @@ def time_cross_attn_kernel(eng, iters=48):
     q = torch.randn(eng.B, 3 * eng.E, device=eng.device)
     args = lambda l: (q.data_ptr(), q.stride(0), eng.k_cross[l].data_ptr(), eng.v_cross[l].data_ptr(), eng.cross_off.data_ptr(),  # noqa: E731
                       eng.cross_len.data_ptr(), eng.partial.data_ptr(), None, 0, eng.B, eng.H, eng.dh, eng.dhp, eng.CROSS_CHUNK,
-                      eng.cross_nsplit, _lib.ACAI_BF16 if eng.bf else _lib.ACAI_F32, 0, ops._st())
+                      eng.cross_nsplit, _lib.ACAI_BF16 if eng.bf else _lib.ACAI_F32, 0, None, ops._st())
     for l in range(eng.L):
         _lib.check(L.acai_decode_attn(*args(l)), "acai_decode_attn")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -102,6 +102,7 @@ typedef struct {
     int32_t *step;                      /* device scalar t: next position to fill (starts at 1) */
     int32_t *finished;                  /* [B] flags + [B] = count of unfinished rows after the step */
     float *x, *xn, *qkv, *attn, *proj, *hid, *logits, *partial; /* workspaces, see DESIGN.md */
+    uint32_t *tickets;                  /* B*H zeroed arrival counters for the in-launch split merge; NULL = separate combine launch */
     float *stats;                       /* 6*B floats: published LayerNorm (mean, rstd) rows; NULL disables the fused-LN path */
 } AcaiDecoder;
 
@@ -131,10 +132,12 @@ int acai_skinny_gemm_ex(const void *x, int ldx, int x_dtype, const void *W, int 
 /* CachedMultiheadAttention.cached_forward's SDPA (K:131-136) for one query per sequence:
  * keys/values of sequence b, head h at kc/vc + seq_off[b] + (h*seq_len[b] + s)*dhp; out[b, h*dh + d] fp32.
  * partial: workspace of B*H*nsplit*(dhp+2) floats; chunk*nsplit must cover max(seq_len).
- * out == NULL stops after the split partials (m, l, o[dhp]) - the streaming kernel alone, for benchmarking. */
+ * out == NULL stops after the split partials (m, l, o[dhp]) - the streaming kernel alone, for benchmarking.
+ * tickets: NULL = a second launch merges the splits; else B*H zeroed counters: the last-arriving workgroup of each (b,h)
+ * merges them inside the launch (agent-scope release / acquire hand-off) and re-zeroes its counter. */
 int acai_decode_attn(const float *q, int ldq, const void *kc, const void *vc, const int64_t *seq_off, const int32_t *seq_len,
                      float *partial, float *out, int ldo, int B, int H, int dh, int dhp, int chunk, int nsplit, int dtype,
-                     int round_out, void *stream);
+                     int round_out, uint32_t *tickets, void *stream);
 
 /* hipGraph helpers (capture on `stream`, replay). */
 int acai_graph_begin(void *stream);

@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     assert [f for f, _ in _lib.AcaiDecLayer._fields_] == names
     import ctypes
     assert ctypes.sizeof(_lib.AcaiDecLayer) == 8 * len(names)
-    assert ctypes.sizeof(_lib.AcaiDecoder) == 20 * 4 + 8 * 22
+    assert ctypes.sizeof(_lib.AcaiDecoder) == 20 * 4 + 8 * 23
 
 
 def test_ops_refuse_cpu_tensors():

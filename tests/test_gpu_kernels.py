@@ -155,8 +155,9 @@ def test_skinny_gemm(dev, B, N, K, dtype):
 
 
 @pytest.mark.parametrize("H,dh,lens", [(16, 64, [1024, 77, 4096, 1]), (2, 6, [3, 1]), (4, 12, [20, 16, 13]), (1, 32, [700])])
+@pytest.mark.parametrize("fused_merge", [False, True])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_decode_attn(dev, H, dh, lens, dtype):
+def test_decode_attn(dev, H, dh, lens, dtype, fused_merge):
     from acai_omr_amd import ops
     g = torch.Generator().manual_seed(H + dh + sum(lens))
     B = len(lens)
@@ -178,7 +179,7 @@ def test_decode_attn(dev, H, dh, lens, dtype):
         vc[o:o + H * l * dhp].view(H, l, dhp)[..., :dh] = v
         o += H * l * dhp
     out = ops.decode_attn(q.to(dev), kc.to(dev).to(tdt), vc.to(dev).to(tdt), torch.tensor(offs, dtype=torch.int64, device=dev),
-                          torch.tensor(lens, dtype=torch.int32, device=dev), H, dh, dhp, max(lens))
+                          torch.tensor(lens, dtype=torch.int32, device=dev), H, dh, dhp, max(lens), fused_merge=fused_merge)
     for b in range(B):
         for h in range(H):
             s = (q[b, h * dh:(h + 1) * dh].double() @ ks[b][h].double().t()) / math.sqrt(dh)
