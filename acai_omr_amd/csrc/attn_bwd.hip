@@ -1,0 +1,337 @@
+// Varlen attention BACKWARD (autograd of the SDPA inside nn.MultiheadAttention: MAE pre-training backward,
+// acai_omr/train/pre_train.py:59; teacher-forced backward, acai_omr/train/omr_teacher_force_train.py:118).
+//
+// Flash-style recompute from Q, K, V and the forward's log-sum-exp; no N x N tensor, no atomics, deterministic.
+// Two kernels with the forward's MFMA machinery (32x32 tiles; the lane-owned side sits in registers as the B operand, the
+// streamed side in LDS as the A operand; an accumulator tile is the next MFMA's B operand without touching LDS):
+//   attn_bwd_dq  : workgroup = 128 queries (query on the lane), streams 64-key tiles:
+//                    S^T = K Q^T, P^T = 2^(c S^T - lse),  dP^T = V dO^T,  dS^T = P^T o (dP^T - delta),  dQ^T += K^T dS^T
+//   attn_bwd_dkv : workgroup = 128 keys (key on the lane), streams 64-query tiles:
+//                    S = Q K^T,  P,  dV^T += dO^T P,  dP = dO V^T,  dS = P o (dP - delta),  dK^T += Q^T dS
+// delta[q] = sum_d dO[q,d] O[q,d] comes from attn_delta_kernel.  S and P are recomputed in both kernels (7 products instead
+// of 5) - the price of having no cross-workgroup reduction.  fp32: v_mfma_f32_32x32x2_f32, bf16: v_mfma_f32_32x32x16_bf16.
+#include "common.h"
+
+namespace {
+
+constexpr int TT = 64;   // streamed-side rows per tile
+constexpr int OB = 128;  // lane-owned rows per workgroup
+
+struct BwdArgs {
+    const void *q, *k, *v, *o, *dout;
+    void *dq, *dk, *dv;
+    const float *lse, *delta;  // [H][total_q]
+    const int32_t *cu_q, *cu_k;
+    int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, H, dh, causal, total_q;
+    float scale_log2e, scale;
+};
+
+template <typename T, bool FAST>
+__device__ __forceinline__ uint4 ld16(const T *base, int ld, int row, int rows, int d0, int dh) {
+    constexpr int EPC = 16 / sizeof(T);
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (row >= rows) return r;
+    if constexpr (FAST) {
+        if (d0 < dh) r = *reinterpret_cast<const uint4 *>(base + (size_t)row * ld + d0);
+    } else {
+        union { uint4 v; T e[EPC]; } u;
+        u.v = r;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+            if (d0 + e < dh) u.e[e] = base[(size_t)row * ld + d0 + e];
+        r = u.v;
+    }
+    return r;
+}
+
+// acc (32 x 32, rows in registers) += A(LDS rows, contraction-contiguous) . B(register fragments)
+template <typename T, int NS>
+__device__ __forceinline__ void mma_rows(f32x16 &acc, const unsigned char *a_rows, int pitch, int lr, int lh, const uint4 (&bf)[NS]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const uint4 af = *reinterpret_cast<const uint4 *>(a_rows + lr * pitch + s * 32 + lh * 16);
+        if constexpr (sizeof(T) == 2) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf[s]), acc, 0, 0, 0);
+        } else {
+            const f32x4 a4 = __builtin_bit_cast(f32x4, af), b4 = __builtin_bit_cast(f32x4, bf[s]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc, 0, 0, 0);
+        }
+    }
+}
+
+// acc[d][lane] += A^T(LDS, [d][r] with the 32 contraction rows r contiguous from byte r0) . X, X = a 32x32 accumulator tile whose rows are r
+template <typename T>
+__device__ __forceinline__ void mma_acc(f32x16 &acc, const unsigned char *at_row, int lh, const f32x16 &x) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            uint4 xf;
+            xf.x = pack_bf16(x[8 * s2 + 0], x[8 * s2 + 1]);
+            xf.y = pack_bf16(x[8 * s2 + 2], x[8 * s2 + 3]);
+            xf.z = pack_bf16(x[8 * s2 + 4], x[8 * s2 + 5]);
+            xf.w = pack_bf16(x[8 * s2 + 6], x[8 * s2 + 7]);
+            const unsigned char *p = at_row + (16 * s2 + 4 * lh) * 2;
+            const uint2 lo = *reinterpret_cast<const uint2 *>(p), hi = *reinterpret_cast<const uint2 *>(p + 16);
+            const uint4 af = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, xf), acc, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4 *>(at_row + (8 * g4 + 4 * lh) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], x[4 * g4 + e], acc, 0, 0, 0);
+        }
+    }
+}
+
+// delta[h][q] = sum_d dO[q, h*dh + d] * O[q, h*dh + d]; one wave per (q, h) pair group
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T *o, int ldo, const T *dout, int lddo, float *delta, int total_q, int H, int dh) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total_q * H) return;
+    const int q = idx / H, h = idx - q * H;
+    const T *po = o + (size_t)q * ldo + h * dh, *pd = dout + (size_t)q * lddo + h * dh;
+    float s = 0.f;
+    for (int d = 0; d < dh; ++d) s += DT<T>::ld(po + d) * DT<T>::ld(pd + d);
+    delta[(size_t)h * total_q + q] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int DHP, bool FAST>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
+    constexpr int ES = sizeof(T), EPC = 16 / ES;
+    constexpr int RP = DHP * ES + 16;   // pitch of row-major tiles [row][d]
+    constexpr int TP = TT * ES + 16;    // pitch of transposed tiles [d][row]
+    constexpr int NS = DHP * ES / 32, NDB = DHP / 32, CPR = DHP / EPC, NCH = TT * CPR / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *ldsK = smem, *ldsV = smem + TT * RP, *ldsKT = smem + 2 * TT * RP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q_start = a.cu_q[b], lq = a.cu_q[b + 1] - q_start;
+    const int k_start = a.cu_k[b], lk = a.cu_k[b + 1] - k_start;
+    const int q0 = blockIdx.x * OB;
+    if (q0 >= lq) return;
+    const int dh = a.dh;
+    const T *Q = reinterpret_cast<const T *>(a.q) + (size_t)q_start * a.ldq + h * dh;
+    const T *K = reinterpret_cast<const T *>(a.k) + (size_t)k_start * a.ldk + h * dh;
+    const T *V = reinterpret_cast<const T *>(a.v) + (size_t)k_start * a.ldv + h * dh;
+    const T *DO = reinterpret_cast<const T *>(a.dout) + (size_t)q_start * a.lddo + h * dh;
+    T *DQ = reinterpret_cast<T *>(a.dq) + (size_t)q_start * a.lddq + h * dh;
+
+    const int my_q = q0 + wave * 32 + lr;
+    uint4 qf[NS], dof[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        qf[s] = ld16<T, FAST>(Q, a.ldq, my_q, lq, (s * 32 + lh * 16) / ES, dh);
+        dof[s] = ld16<T, FAST>(DO, a.lddo, my_q, lq, (s * 32 + lh * 16) / ES, dh);
+    }
+    const size_t sidx = (size_t)h * a.total_q + q_start + (my_q < lq ? my_q : 0);
+    const float lse = a.lse[sidx], dlt = a.delta[sidx];
+
+    f32x16 dqacc[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dqacc[d][e] = 0.f;
+
+    int nkt = (lk + TT - 1) / TT;
+    if (a.causal) nkt = min(nkt, (min(q0 + OB, lq) - 1) / TT + 1);
+    for (int kt = 0; kt < nkt; ++kt) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 256 * i, row = c / CPR, cc = c % CPR;
+            const uint4 rk = ld16<T, FAST>(K, a.ldk, kt * TT + row, lk, cc * EPC, dh);
+            const uint4 rv = ld16<T, FAST>(V, a.ldv, kt * TT + row, lk, cc * EPC, dh);
+            *reinterpret_cast<uint4 *>(ldsK + row * RP + cc * 16) = rk;
+            *reinterpret_cast<uint4 *>(ldsV + row * RP + cc * 16) = rv;
+            union { uint4 v; T e[EPC]; } u;
+            u.v = rk;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) *reinterpret_cast<T *>(ldsKT + (cc * EPC + e) * TP + row * ES) = u.e[e];
+        }
+        __syncthreads();
+        const int key_lim = a.causal ? min(lk, my_q + 1) : lk;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 sacc, dpacc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[e] = dpacc[e] = 0.f;
+            mma_rows<T, NS>(sacc, ldsK + kb * 32 * RP, RP, lr, lh, qf);     // S^T[key][q]
+            mma_rows<T, NS>(dpacc, ldsV + kb * 32 * RP, RP, lr, lh, dof);   // dP^T[key][q]
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kt * TT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const float p = key < key_lim ? exp2f(sacc[e] * a.scale_log2e - lse) : 0.f;
+                sacc[e] = p * (dpacc[e] - dlt);                            // dS^T
+            }
+#pragma unroll
+            for (int d = 0; d < NDB; ++d) mma_acc<T>(dqacc[d], ldsKT + (d * 32 + lr) * TP + kb * 32 * ES, lh, sacc);  // dQ^T += K^T dS^T
+        }
+        __syncthreads();
+    }
+    if (my_q < lq) {
+        T *row = DQ + (size_t)my_q * a.lddq;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int dd = d * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (dd < dh) DT<T>::st(row + dd, dqacc[d][e] * a.scale);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int DHP, bool FAST>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
+    constexpr int ES = sizeof(T), EPC = 16 / ES;
+    constexpr int RP = DHP * ES + 16, TP = TT * ES + 16;
+    constexpr int NS = DHP * ES / 32, NDB = DHP / 32, CPR = DHP / EPC, NCH = TT * CPR / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *ldsQ = smem, *ldsDO = smem + TT * RP, *ldsQT = smem + 2 * TT * RP, *ldsDOT = ldsQT + DHP * TP;
+    float *ldsLse = reinterpret_cast<float *>(ldsDOT + DHP * TP), *ldsDlt = ldsLse + TT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q_start = a.cu_q[b], lq = a.cu_q[b + 1] - q_start;
+    const int k_start = a.cu_k[b], lk = a.cu_k[b + 1] - k_start;
+    const int k0 = blockIdx.x * OB;
+    if (k0 >= lk) return;
+    const int dh = a.dh;
+    const T *Q = reinterpret_cast<const T *>(a.q) + (size_t)q_start * a.ldq + h * dh;
+    const T *K = reinterpret_cast<const T *>(a.k) + (size_t)k_start * a.ldk + h * dh;
+    const T *V = reinterpret_cast<const T *>(a.v) + (size_t)k_start * a.ldv + h * dh;
+    const T *DO = reinterpret_cast<const T *>(a.dout) + (size_t)q_start * a.lddo + h * dh;
+    T *DK = reinterpret_cast<T *>(a.dk) + (size_t)k_start * a.lddk + h * dh;
+    T *DV = reinterpret_cast<T *>(a.dv) + (size_t)k_start * a.lddv + h * dh;
+
+    const int my_k = k0 + wave * 32 + lr;
+    uint4 kf[NS], vf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        kf[s] = ld16<T, FAST>(K, a.ldk, my_k, lk, (s * 32 + lh * 16) / ES, dh);
+        vf[s] = ld16<T, FAST>(V, a.ldv, my_k, lk, (s * 32 + lh * 16) / ES, dh);
+    }
+    f32x16 dkacc[NDB], dvacc[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dkacc[d][e] = dvacc[d][e] = 0.f;
+
+    const int nqt = (lq + TT - 1) / TT;
+    const int qt0 = a.causal ? k0 / TT : 0;  // queries before this key block never attend to it
+    for (int qt = qt0; qt < nqt; ++qt) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 256 * i, row = c / CPR, cc = c % CPR;
+            const uint4 rq = ld16<T, FAST>(Q, a.ldq, qt * TT + row, lq, cc * EPC, dh);
+            const uint4 rd = ld16<T, FAST>(DO, a.lddo, qt * TT + row, lq, cc * EPC, dh);
+            *reinterpret_cast<uint4 *>(ldsQ + row * RP + cc * 16) = rq;
+            *reinterpret_cast<uint4 *>(ldsDO + row * RP + cc * 16) = rd;
+            union { uint4 v; T e[EPC]; } uq, ud;
+            uq.v = rq;
+            ud.v = rd;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                *reinterpret_cast<T *>(ldsQT + (cc * EPC + e) * TP + row * ES) = uq.e[e];
+                *reinterpret_cast<T *>(ldsDOT + (cc * EPC + e) * TP + row * ES) = ud.e[e];
+            }
+        }
+        if (tid < TT) {
+            const int qq = qt * TT + tid;
+            const size_t sidx = (size_t)h * a.total_q + q_start + (qq < lq ? qq : 0);
+            ldsLse[tid] = a.lse[sidx];
+            ldsDlt[tid] = a.delta[sidx];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 sacc, dpacc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[e] = dpacc[e] = 0.f;
+            mma_rows<T, NS>(sacc, ldsQ + qb * 32 * RP, RP, lr, lh, kf);      // S[q][key]
+            mma_rows<T, NS>(dpacc, ldsDO + qb * 32 * RP, RP, lr, lh, vf);    // dP[q][key]
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ql = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, qq = qt * TT + ql;
+                const bool ok = qq < lq && my_k < lk && (!a.causal || my_k <= qq);
+                const float p = ok ? exp2f(sacc[e] * a.scale_log2e - ldsLse[ql]) : 0.f;
+                sacc[e] = p;                                  // P
+                dpacc[e] = p * (dpacc[e] - ldsDlt[ql]);       // dS
+            }
+#pragma unroll
+            for (int d = 0; d < NDB; ++d) {
+                mma_acc<T>(dvacc[d], ldsDOT + (d * 32 + lr) * TP + qb * 32 * ES, lh, sacc);   // dV^T += dO^T P
+                mma_acc<T>(dkacc[d], ldsQT + (d * 32 + lr) * TP + qb * 32 * ES, lh, dpacc);   // dK^T += Q^T dS
+            }
+        }
+        __syncthreads();
+    }
+    if (my_k < lk) {
+        T *rk = DK + (size_t)my_k * a.lddk, *rv = DV + (size_t)my_k * a.lddv;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int dd = d * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (dd < dh) {
+                    DT<T>::st(rk + dd, dkacc[d][e] * a.scale);
+                    DT<T>::st(rv + dd, dvacc[d][e]);
+                }
+            }
+    }
+}
+
+template <typename T, int DHP>
+int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, hipStream_t st) {
+    constexpr int ES = sizeof(T), EPC = 16 / ES;
+    const bool fast = (a.dh % EPC == 0) && (a.ldq % EPC == 0) && (a.ldk % EPC == 0) && (a.ldv % EPC == 0) && (a.lddo % EPC == 0) &&
+                      aligned16(a.q) && aligned16(a.k) && aligned16(a.v) && aligned16(a.dout);
+    constexpr int RP = DHP * ES + 16, TP = TT * ES + 16;
+    const size_t lds_dq = 2 * TT * RP + DHP * TP, lds_dkv = 2 * TT * RP + 2 * DHP * TP + 2 * TT * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_kernel<T, DHP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_kernel<T, DHP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_kernel<T, DHP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_kernel<T, DHP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(cdiv(a.total_q * a.H, 256)), dim3(256), 0, st, (const T *)a.o, a.ldo, (const T *)a.dout, a.lddo,
+                       const_cast<float *>(a.delta), a.total_q, a.H, a.dh);
+    ACAI_LAUNCH_CHECK("attn_delta");
+    dim3 gq(cdiv(max_q, OB), a.H, B), gk(cdiv(max_k, OB), a.H, B);
+    if (fast) {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DHP, true>), gq, dim3(256), lds_dq, st, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DHP, true>), gk, dim3(256), lds_dkv, st, a);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DHP, false>), gq, dim3(256), lds_dq, st, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DHP, false>), gk, dim3(256), lds_dkv, st, a);
+    }
+    ACAI_LAUNCH_CHECK("acai_attn_varlen_bwd");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int acai_attn_varlen_bwd(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, const void *o, int ldo,
+                                    const void *dout, int lddo, void *dq, int lddq, void *dk, int lddk, void *dv, int lddv, const float *lse,
+                                    float *delta, const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int max_k,
+                                    int total_q, int causal, int dtype, void *stream) {
+    ACAI_CHECK_ARG(q && k && v && o && dout && dq && dk && dv && lse && delta && cu_q && cu_k, "acai_attn_varlen_bwd: null operand");
+    ACAI_CHECK_ARG(B > 0 && H > 0 && dh > 0 && dh <= 64 && max_q > 0 && max_k > 0 && total_q > 0 && B <= 65535 && H <= 65535,
+                   "acai_attn_varlen_bwd: bad dims");
+    BwdArgs a{};
+    a.q = q; a.k = k; a.v = v; a.o = o; a.dout = dout; a.dq = dq; a.dk = dk; a.dv = dv; a.lse = lse; a.delta = delta; a.cu_q = cu_q; a.cu_k = cu_k;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+    a.H = H; a.dh = dh; a.causal = causal; a.total_q = total_q;
+    a.scale = 1.0f / sqrtf((float)dh);
+    a.scale_log2e = 1.4426950408889634f * a.scale;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ACAI_BF16) return dh <= 32 ? launch_bwd<bf16_t, 32>(a, B, max_q, max_k, st) : launch_bwd<bf16_t, 64>(a, B, max_q, max_k, st);
+    if (dtype == ACAI_F32) return dh <= 32 ? launch_bwd<float, 32>(a, B, max_q, max_k, st) : launch_bwd<float, 64>(a, B, max_q, max_k, st);
+    return acai_set_err(-1, "acai_attn_varlen_bwd: bad dtype %d", dtype);
+}

@@ -27,6 +27,8 @@ struct AttnArgs {
     const int32_t *cu_q, *cu_k;
     int ldq, ldk, ldv, ldo, H, dh, causal;
     float scale_log2e;
+    float *lse;   // optional [H][total_q]: log2-domain log-sum-exp of the scaled scores (saved for the backward pass)
+    int total_q;
 };
 
 template <typename T, int DHP, bool FAST>
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     // ---- normalise and store: lane owns query my_q, registers hold d = db*32 + (e&3) + 8*(e>>2) + 4*lh ------
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (a.lse && my_q < lq && lh == 0) a.lse[(size_t)h * a.total_q + q_start + my_q] = m_run + log2f(l_tot);
     if (my_q < lq) {
         T *orow = O + (size_t)my_q * a.ldo;
 #pragma unroll
@@ -265,12 +268,12 @@ int launch(const AttnArgs &a, int B, int max_q, hipStream_t st) {
 
 extern "C" int acai_attn_varlen_fwd(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, void *out, int ldo,
                                     const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int causal,
-                                    int dtype, void *stream) {
+                                    int dtype, float *lse, int total_q, void *stream) {
     ACAI_CHECK_ARG(q && k && v && out && cu_q && cu_k, "acai_attn_varlen_fwd: null operand");
     ACAI_CHECK_ARG(B > 0 && H > 0 && dh > 0 && dh <= 64 && max_q > 0, "acai_attn_varlen_fwd: bad dims B=%d H=%d dh=%d max_q=%d (dh <= 64)", B, H, dh, max_q);
     ACAI_CHECK_ARG(ldq >= H * dh && ldk >= H * dh && ldv >= H * dh && ldo >= H * dh, "acai_attn_varlen_fwd: row stride smaller than H*dh");
     ACAI_CHECK_ARG(B <= 65535 && H <= 65535, "acai_attn_varlen_fwd: grid too large");
-    AttnArgs a{q, k, v, out, cu_q, cu_k, ldq, ldk, ldv, ldo, H, dh, causal, 0.f};
+    AttnArgs a{q, k, v, out, cu_q, cu_k, ldq, ldk, ldv, ldo, H, dh, causal, 0.f, lse, total_q};
     a.scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ACAI_BF16) return dh <= 32 ? launch<bf16_t, 32>(a, B, max_q, st) : launch<bf16_t, 64>(a, B, max_q, st);

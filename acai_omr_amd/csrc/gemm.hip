@@ -46,7 +46,28 @@ __device__ __forceinline__ uint4 load_chunk(const T *base, int ld, int row, int 
     return r;
 }
 
-template <typename T, int EPI, bool FAST>
+// Transposed storage (backward GEMMs: dX = dY.W reads W as [K][N]; dW = dY^T.X reads both operands reduction-major):
+// the operand is stored [k][row] with `row` contiguous.  A thread still owns one 16-byte global chunk (EPC consecutive
+// rows at one k) and scatters its elements into EPC LDS rows, so the LDS image and the MFMA loop are unchanged.
+template <typename T, bool FAST>
+__device__ __forceinline__ uint4 load_chunk_t(const T *base, int ld, int k, int K, int row0, int rows) {
+    constexpr int EPC = 16 / sizeof(T);
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (k >= K) return r;
+    if constexpr (FAST) {
+        if (row0 < rows) r = *reinterpret_cast<const uint4 *>(base + (size_t)k * ld + row0);
+    } else {
+        union { uint4 v; T e[EPC]; } u;
+        u.v = r;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+            if (row0 + e < rows) u.e[e] = base[(size_t)k * ld + row0 + e];
+        r = u.v;
+    }
+    return r;
+}
+
+template <typename T, int EPI, bool FAST, bool TA = false, bool TB = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     constexpr int EPC = 16 / sizeof(T);     // elements per 16-byte chunk
     constexpr int BK = ROWB / sizeof(T);    // k elements per tile
@@ -81,20 +102,38 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     uint4 ra[4], rb[4];
     const int nkt = (g.K + BK - 1) / BK;
 
+    // transposed staging: chunk c -> k index c / (128/EPC), row group c % (128/EPC) (consecutive lanes walk the contiguous dim)
+    constexpr int RG = 128 / EPC;  // 16-byte row groups per 128-row tile
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = tid + 256 * i, row = c >> 3, k0 = kt * BK + (c & 7) * EPC;
-            ra[i] = load_chunk<T, FAST>(A, g.lda, bm0 + row, g.M, k0, g.K);
-            rb[i] = load_chunk<T, FAST>(W, g.ldw, bn0 + row, g.N, k0, g.K);
+            if constexpr (TA) ra[i] = load_chunk_t<T, FAST>(A, g.lda, kt * BK + c / RG, g.K, bm0 + (c % RG) * EPC, g.M);
+            else ra[i] = load_chunk<T, FAST>(A, g.lda, bm0 + row, g.M, k0, g.K);
+            if constexpr (TB) rb[i] = load_chunk_t<T, FAST>(W, g.ldw, kt * BK + c / RG, g.K, bn0 + (c % RG) * EPC, g.N);
+            else rb[i] = load_chunk<T, FAST>(W, g.ldw, bn0 + row, g.N, k0, g.K);
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = tid + 256 * i, row = c >> 3, cb = (c & 7) * 16;
-            *reinterpret_cast<uint4 *>(lds + row * PITCH + cb) = ra[i];
-            *reinterpret_cast<uint4 *>(lds + (BM + row) * PITCH + cb) = rb[i];
+            if constexpr (TA) {
+                union { uint4 v; T e[EPC]; } u;
+                u.v = ra[i];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) *reinterpret_cast<T *>(lds + ((c % RG) * EPC + e) * PITCH + (c / RG) * sizeof(T)) = u.e[e];
+            } else {
+                *reinterpret_cast<uint4 *>(lds + row * PITCH + cb) = ra[i];
+            }
+            if constexpr (TB) {
+                union { uint4 v; T e[EPC]; } u;
+                u.v = rb[i];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) *reinterpret_cast<T *>(lds + (BM + (c % RG) * EPC + e) * PITCH + (c / RG) * sizeof(T)) = u.e[e];
+            } else {
+                *reinterpret_cast<uint4 *>(lds + (BM + row) * PITCH + cb) = rb[i];
+            }
         }
     };
 
@@ -178,16 +217,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     }
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, bool TA = false, bool TB = false>
 int launch(const GemmArgs &g, hipStream_t st) {
     constexpr int EPC = 16 / sizeof(T);
-    const bool fast = (g.K % EPC == 0) && (g.lda % EPC == 0) && (g.ldw % EPC == 0) && aligned16(g.A) && aligned16(g.W);
+    // 16-byte chunks run along K for row-major operands and along the row index for transposed ones
+    const bool fast = (g.lda % EPC == 0) && (g.ldw % EPC == 0) && aligned16(g.A) && aligned16(g.W) && (TA ? g.M % EPC == 0 : g.K % EPC == 0) &&
+                      (TB ? g.N % EPC == 0 : g.K % EPC == 0);
     const int nwg = cdiv(g.M, BM) * cdiv(g.N, BN);
     if (fast)
-        hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, true>), dim3(nwg), dim3(256), 0, st, g);
+        hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, true, TA, TB>), dim3(nwg), dim3(256), 0, st, g);
     else
-        hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, false>), dim3(nwg), dim3(256), 0, st, g);
-    ACAI_LAUNCH_CHECK("acai_gemm_nt");
+        hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, false, TA, TB>), dim3(nwg), dim3(256), 0, st, g);
+    ACAI_LAUNCH_CHECK("acai_gemm");
     return 0;
 }
 
@@ -206,6 +247,39 @@ extern "C" int acai_gemm_nt(const void *A, int lda, const void *W, int ldw, cons
     g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.out_dtype = out_dtype; g.flags = flags;
     return in_dtype == ACAI_BF16 ? launch<bf16_t, 0>(g, (hipStream_t)stream) : launch<float, 0>(g, (hipStream_t)stream);
+}
+
+// General form for the backward pass: C[M,N] = op(A) . op(W)^T (+bias) (+residual), logical A [M,K], logical W [N,K];
+// trans_a: A is stored [K][M] (lda = row stride of that storage); trans_w: W is stored [K][N].
+//   dX = dY . W       : A = dY [M,N'] row-major,  W stored [N'][K'] = "[K_red][N_out]" -> trans_w = 1
+//   dW = dY^T . X     : A = dY stored [M_red][N] -> trans_a = 1;  W-operand = X stored [M_red][K] -> trans_w = 1
+extern "C" int acai_gemm(const void *A, int lda, int trans_a, const void *W, int ldw, int trans_w, const float *bias, const float *residual,
+                         int ldr, void *C, int ldc, int M, int N, int K, int in_dtype, int out_dtype, int flags, void *stream) {
+    ACAI_CHECK_ARG(A && W && C, "acai_gemm: null operand");
+    ACAI_CHECK_ARG(M >= 0 && N > 0 && K > 0, "acai_gemm: bad shape M=%d N=%d K=%d", M, N, K);
+    ACAI_CHECK_ARG(lda >= (trans_a ? M : K) && ldw >= (trans_w ? N : K) && ldc >= N && (!residual || ldr >= N), "acai_gemm: leading dimension smaller than row");
+    ACAI_CHECK_ARG((in_dtype == ACAI_F32 || in_dtype == ACAI_BF16) && (out_dtype == ACAI_F32 || out_dtype == ACAI_BF16), "acai_gemm: bad dtype");
+    if (M == 0) return 0;
+    GemmArgs g{};
+    g.A = A; g.W = W; g.bias = bias; g.residual = residual; g.C = C;
+    g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.out_dtype = out_dtype; g.flags = flags;
+    hipStream_t st = (hipStream_t)stream;
+    const int sel = (trans_a ? 2 : 0) | (trans_w ? 1 : 0);
+    if (in_dtype == ACAI_BF16) {
+        switch (sel) {
+            case 0: return launch<bf16_t, 0, false, false>(g, st);
+            case 1: return launch<bf16_t, 0, false, true>(g, st);
+            case 2: return launch<bf16_t, 0, true, false>(g, st);
+            default: return launch<bf16_t, 0, true, true>(g, st);
+        }
+    }
+    switch (sel) {
+        case 0: return launch<float, 0, false, false>(g, st);
+        case 1: return launch<float, 0, false, true>(g, st);
+        case 2: return launch<float, 0, true, false>(g, st);
+        default: return launch<float, 0, true, true>(g, st);
+    }
 }
 
 extern "C" int acai_cross_kv_prefill(const void *mem, int ldm, const void *Wkv, int ldw, const float *bkv, const int32_t *row_seq,

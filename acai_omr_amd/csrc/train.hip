@@ -1,0 +1,238 @@
+// Row kernels of the backward pass and the two losses (HBM-bound, fp32 math):
+//   LayerNorm backward (autograd of nn.LayerNorm, models.py:33 and the norm1/2/3 of every block), exact-erf GELU forward /
+//   backward as stand-alone passes (training keeps the pre-activation), column sums (bias gradients), row scatter-add
+//   (gradients of nn.Embedding, pos_embedding slices, MAE shuffle), MAELoss (models.py:271-288) and OMRCELoss
+//   (models.py:784-796) forward + backward in one pass each.
+#include "common.h"
+
+namespace {
+
+// ---- LayerNorm backward ------------------------------------------------------------------------------------------------
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w,  xhat = (x - mean) * rstd;  stats[row] = (mean, rstd) for the
+// parameter-gradient pass.  One wave per row, statistics recomputed from x (two-pass, as the forward).
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ dy,
+                                                        float eps, float *dx, float *stats, int rows, int dim) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + (size_t)row * dim, *gr = dy + (size_t)row * dim;
+    float s = 0.f;
+    for (int i = lane; i < dim; i += 64) s += xr[i];
+    const float mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+    for (int i = lane; i < dim; i += 64) {
+        const float d = xr[i] - mean;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)dim + eps);
+    float sg = 0.f, sgx = 0.f;
+    for (int i = lane; i < dim; i += 64) {
+        const float g = gr[i] * w[i], xh = (xr[i] - mean) * rstd;
+        sg += g;
+        sgx += g * xh;
+    }
+    sg = wave_sum(sg) / (float)dim;
+    sgx = wave_sum(sgx) / (float)dim;
+    for (int i = lane; i < dim; i += 64) {
+        const float g = gr[i] * w[i], xh = (xr[i] - mean) * rstd;
+        dx[(size_t)row * dim + i] = rstd * (g - sg - xh * sgx);
+    }
+    if (lane == 0) {
+        stats[row * 2] = mean;
+        stats[row * 2 + 1] = rstd;
+    }
+}
+
+// dw[c] += sum_r dy[r,c] * xhat[r,c], db[c] += sum_r dy[r,c]; grid (col tiles of 64, row chunks), fp32 atomics per workgroup.
+__global__ __launch_bounds__(256) void ln_bwd_param_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ stats,
+                                                           float *dw, float *db, int rows, int dim, int rows_per_block) {
+    __shared__ float sw[4][64], sb[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float aw = 0.f, ab = 0.f;
+    if (c < dim)
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const float g = dy[(size_t)r * dim + c];
+            aw += g * (x[(size_t)r * dim + c] - stats[r * 2]) * stats[r * 2 + 1];
+            ab += g;
+        }
+    sw[wave][lane] = aw;
+    sb[wave][lane] = ab;
+    __syncthreads();
+    if (wave == 0 && c < dim) {
+        atomicAdd(dw + c, sw[0][lane] + sw[1][lane] + sw[2][lane] + sw[3][lane]);
+        atomicAdd(db + c, sb[0][lane] + sb[1][lane] + sb[2][lane] + sb[3][lane]);
+    }
+}
+
+// ---- GELU ----------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const T *__restrict__ a, T *h, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) DT<T>::st(h + i, gelu_erf(DT<T>::ld(a + i)));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T *__restrict__ a, const T *__restrict__ dh, T *da, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float x = DT<T>::ld(a + i);
+        const float g = 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+        DT<T>::st(da + i, DT<T>::ld(dh + i) * g);
+    }
+}
+
+// ---- column sum: out[c] += sum_r x[r,c] ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ x, int ld, float *out, int rows, int cols, int rows_per_block) {
+    __shared__ float s[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float acc = 0.f;
+    if (c < cols)
+        for (int r = r0 + wave; r < r1; r += 4) acc += DT<T>::ld(x + (size_t)r * ld + c);
+    s[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < cols) atomicAdd(out + c, s[0][lane] + s[1][lane] + s[2][lane] + s[3][lane]);
+}
+
+// ---- dst[idx[r], :] += src[r, :] -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float *__restrict__ src, const int32_t *__restrict__ idx, float *dst, int rows, int dim) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *s = src + (size_t)row * dim;
+    float *d = dst + (size_t)idx[row] * dim;
+    for (int i = lane; i < dim; i += 64) atomicAdd(d + i, s[i]);
+}
+
+// ---- MAELoss fwd + bwd: loss += mask * mean_d((pred - that)^2) * inv_count, dpred = 2 (pred - that) / D * mask * inv_count * gscale
+__global__ __launch_bounds__(256) void mae_loss_kernel(const float *__restrict__ pred, const float *__restrict__ target, const unsigned char *__restrict__ mask,
+                                                       float inv_count, float *loss, float *dpred, int rows, int dim) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *p = pred + (size_t)row * dim, *t = target + (size_t)row * dim;
+    const bool on = mask[row] != 0;
+    if (!on) {
+        if (dpred)
+            for (int i = lane; i < dim; i += 64) dpred[(size_t)row * dim + i] = 0.f;
+        return;
+    }
+    float s = 0.f;
+    for (int i = lane; i < dim; i += 64) s += t[i];
+    const float mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+    for (int i = lane; i < dim; i += 64) {
+        const float d = t[i] - mean;
+        q += d * d;
+    }
+    const float var = wave_sum(q) / (float)(dim - 1);  // Tensor.var default: unbiased (models.py:281)
+    const float rs = 1.0f / sqrtf(var + 1.0e-6f);
+    float e = 0.f;
+    for (int i = lane; i < dim; i += 64) {
+        const float d = p[i] - (t[i] - mean) * rs;
+        e += d * d;
+        if (dpred) dpred[(size_t)row * dim + i] = 2.0f * d / (float)dim * inv_count;
+    }
+    e = wave_sum(e) / (float)dim;
+    if (lane == 0) atomicAdd(loss, e * inv_count);
+}
+
+// ---- OMRCELoss fwd + bwd: rows with target == ignore contribute nothing; mean over the others ------------------------------
+__global__ __launch_bounds__(256) void ce_loss_kernel(const float *__restrict__ logits, int ld, const int64_t *__restrict__ target, int ignore,
+                                                      float inv_count, float *loss, float *dlogits, int rows, int V) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *lg = logits + (size_t)row * ld;
+    const int64_t tg = target[row];
+    if (tg == ignore) {
+        if (dlogits)
+            for (int i = lane; i < V; i += 64) dlogits[(size_t)row * V + i] = 0.f;
+        return;
+    }
+    float m = -INFINITY;
+    for (int i = lane; i < V; i += 64) m = fmaxf(m, lg[i]);
+    m = wave_max(m);
+    float se = 0.f;
+    for (int i = lane; i < V; i += 64) se += expf(lg[i] - m);
+    se = wave_sum(se);
+    const float lse = m + logf(se);
+    if (dlogits)
+        for (int i = lane; i < V; i += 64) dlogits[(size_t)row * V + i] = (expf(lg[i] - lse) - (i == tg ? 1.f : 0.f)) * inv_count;
+    if (lane == 0) atomicAdd(loss, (lse - lg[tg]) * inv_count);
+}
+
+static inline int grid1d(long n) {
+    long g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" int acai_layernorm_bwd(const float *x, const float *w, const float *dy, float eps, float *dx, float *dw, float *db, float *stats,
+                                  int rows, int dim, void *stream) {
+    ACAI_CHECK_ARG(x && w && dy && dx && stats && rows >= 0 && dim > 0, "acai_layernorm_bwd: bad arguments");
+    if (rows == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, w, dy, eps, dx, stats, rows, dim);
+    if (dw && db) {
+        const int rpb = 2048;
+        hipLaunchKernelGGL(ln_bwd_param_kernel, dim3(cdiv(dim, 64), cdiv(rows, rpb)), dim3(256), 0, st, x, dy, stats, dw, db, rows, dim, rpb);
+    }
+    ACAI_LAUNCH_CHECK("acai_layernorm_bwd");
+    return 0;
+}
+
+extern "C" int acai_gelu_fwd(const void *a, void *h, int64_t n, int dtype, void *stream) {
+    ACAI_CHECK_ARG(a && h && n >= 0, "acai_gelu_fwd: bad arguments");
+    if (n == 0) return 0;
+    if (dtype == ACAI_BF16) hipLaunchKernelGGL(gelu_fwd_kernel<bf16_t>, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)a, (bf16_t *)h, (long)n);
+    else hipLaunchKernelGGL(gelu_fwd_kernel<float>, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, (const float *)a, (float *)h, (long)n);
+    ACAI_LAUNCH_CHECK("acai_gelu_fwd");
+    return 0;
+}
+
+extern "C" int acai_gelu_bwd(const void *a, const void *dh, void *da, int64_t n, int dtype, void *stream) {
+    ACAI_CHECK_ARG(a && dh && da && n >= 0, "acai_gelu_bwd: bad arguments");
+    if (n == 0) return 0;
+    if (dtype == ACAI_BF16)
+        hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)a, (const bf16_t *)dh, (bf16_t *)da, (long)n);
+    else
+        hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, (const float *)a, (const float *)dh, (float *)da, (long)n);
+    ACAI_LAUNCH_CHECK("acai_gelu_bwd");
+    return 0;
+}
+
+extern "C" int acai_colsum(const void *x, int ld, float *out, int rows, int cols, int dtype, void *stream) {
+    ACAI_CHECK_ARG(x && out && rows >= 0 && cols > 0 && ld >= cols, "acai_colsum: bad arguments");
+    if (rows == 0) return 0;
+    const int rpb = 2048;
+    dim3 grid(cdiv(cols, 64), cdiv(rows, rpb));
+    if (dtype == ACAI_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t *)x, ld, out, rows, cols, rpb);
+    else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)x, ld, out, rows, cols, rpb);
+    ACAI_LAUNCH_CHECK("acai_colsum");
+    return 0;
+}
+
+extern "C" int acai_scatter_add_rows(const float *src, const int32_t *idx, float *dst, int rows, int dim, void *stream) {
+    ACAI_CHECK_ARG(src && idx && dst && rows >= 0 && dim > 0, "acai_scatter_add_rows: bad arguments");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, src, idx, dst, rows, dim);
+    ACAI_LAUNCH_CHECK("acai_scatter_add_rows");
+    return 0;
+}
+
+extern "C" int acai_mae_loss(const float *pred, const float *target, const unsigned char *mask, float inv_count, float *loss, float *dpred,
+                             int rows, int dim, void *stream) {
+    ACAI_CHECK_ARG(pred && target && mask && loss && rows >= 0 && dim > 1, "acai_mae_loss: bad arguments");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(mae_loss_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, pred, target, mask, inv_count, loss, dpred, rows, dim);
+    ACAI_LAUNCH_CHECK("acai_mae_loss");
+    return 0;
+}
+
+extern "C" int acai_ce_loss(const float *logits, int ld, const int64_t *target, int ignore_index, float inv_count, float *loss, float *dlogits,
+                            int rows, int V, void *stream) {
+    ACAI_CHECK_ARG(logits && target && loss && rows >= 0 && V > 0 && ld >= V, "acai_ce_loss: bad arguments");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(ce_loss_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits, ld, target, ignore_index, inv_count, loss, dlogits, rows, V);
+    ACAI_LAUNCH_CHECK("acai_ce_loss");
+    return 0;
+}

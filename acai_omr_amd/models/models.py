@@ -155,6 +155,9 @@ class Encoder(nn.Module):
 
     def forward(self, x):
         x32, _, lens = self.forward_packed(x)
+        if x32.requires_grad:
+            from ..train import autograd_path
+            return autograd_path.pad_rows(x32, lens, self._pad_fill())
         return EG.pad_rows(x32, lens, self._pad_fill())
 
     def embed_single_image(self, x):

@@ -68,6 +68,24 @@ def gemm_nt(a, w, bias=None, residual=None, out_dtype=torch.float32, gelu=False,
     return out
 
 
+def gemm(a, w, trans_a=False, trans_w=False, bias=None, residual=None, out_dtype=torch.float32, out=None):
+    """out[M,N] = op(a) @ op(w)^T: logical a [M,K] (stored [K,M] if trans_a), logical w [N,K] (stored [K,N] if trans_w)."""
+    _chk(a, "a"), _chk(w, "w")
+    assert a.dim() == 2 and w.dim() == 2 and a.dtype == w.dtype
+    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    N, K2 = (w.shape[1], w.shape[0]) if trans_w else w.shape
+    assert K == K2, (a.shape, w.shape, trans_a, trans_w)
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.shape == (M, N) and residual.stride(1) == 1
+    _lib.check(_lib.lib().acai_gemm(a.data_ptr(), a.stride(0), 1 if trans_a else 0, w.data_ptr(), w.stride(0), 1 if trans_w else 0, _p(bias),
+                                    _p(residual), residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0), M, N, K,
+                                    _dt(a), _dt(out), 0, _st()), "acai_gemm")
+    return out
+
+
 def cast_bf16(x):
     _chk(x, "x", torch.float32)
     assert x.is_contiguous()
@@ -100,7 +118,7 @@ def gather_rows(table, idx, add=None, out=None):
     return out
 
 
-def attn_varlen(q, k, v, cu_q, cu_k, H, dh, max_q, causal=False, out=None):
+def attn_varlen(q, k, v, cu_q, cu_k, H, dh, max_q, causal=False, out=None, lse=None):
     """q [Mq, >=H*dh], k/v [Mk, >=H*dh] (2-D views with any row stride), cu_* int32 [B+1] on the GPU."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _chk(t, n)
@@ -113,7 +131,7 @@ def attn_varlen(q, k, v, cu_q, cu_k, H, dh, max_q, causal=False, out=None):
     assert out.shape[0] == q.shape[0] and out.stride(1) == 1 and out.dtype == q.dtype
     _lib.check(_lib.lib().acai_attn_varlen_fwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
                                                out.data_ptr(), out.stride(0), cu_q.data_ptr(), cu_k.data_ptr(), B, H, dh, int(max_q),
-                                               1 if causal else 0, _dt(q), _st()), "acai_attn_varlen_fwd")
+                                               1 if causal else 0, _dt(q), _p(lse), q.shape[0], _st()), "acai_attn_varlen_fwd")
     return out
 
 
@@ -173,6 +191,87 @@ def decode_attn(q, kc, vc, seq_off, seq_len, H, dh, dhp, max_len, round_out=Fals
     if tickets is not None:
         assert int(tickets.abs().sum().item()) == 0, "arrival counters must re-arm to zero"
     return out
+
+
+def attn_varlen_bwd(q, k, v, o, dout, lse, cu_q, cu_k, H, dh, max_q, max_k, causal, dq, dk, dv):
+    """Gradients of attn_varlen w.r.t. q, k, v, written into the (strided) views dq, dk, dv."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (dout, "dout"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        _chk(t, n)
+        assert t.dim() == 2 and t.dtype == q.dtype, n
+    _chk(lse, "lse", torch.float32)
+    B = cu_q.numel() - 1
+    total_q = q.shape[0]
+    assert lse.numel() == H * total_q and dout.shape == o.shape
+    delta = torch.empty(H * total_q, dtype=torch.float32, device=q.device)
+    _lib.check(_lib.lib().acai_attn_varlen_bwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), o.data_ptr(), o.stride(0),
+                                               dout.data_ptr(), dout.stride(0), dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(),
+                                               dv.stride(0), lse.data_ptr(), delta.data_ptr(), cu_q.data_ptr(), cu_k.data_ptr(), B, H, dh, int(max_q),
+                                               int(max_k), total_q, 1 if causal else 0, _dt(q), _st()), "acai_attn_varlen_bwd")
+
+
+def layernorm_bwd(x, w, dy, eps, want_param_grads=True):
+    _chk(x, "x", torch.float32), _chk(dy, "dy", torch.float32)
+    assert x.is_contiguous() and dy.is_contiguous() and x.shape == dy.shape
+    rows, dim = x.shape
+    dx = torch.empty_like(x)
+    stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+    dw = torch.zeros(dim, dtype=torch.float32, device=x.device) if want_param_grads else None
+    db = torch.zeros(dim, dtype=torch.float32, device=x.device) if want_param_grads else None
+    _lib.check(_lib.lib().acai_layernorm_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), float(eps), dx.data_ptr(), _p(dw), _p(db), stats.data_ptr(),
+                                             rows, dim, _st()), "acai_layernorm_bwd")
+    return dx, dw, db
+
+
+def gelu_fwd(a):
+    _chk(a, "a")
+    assert a.is_contiguous()
+    h = torch.empty_like(a)
+    _lib.check(_lib.lib().acai_gelu_fwd(a.data_ptr(), h.data_ptr(), a.numel(), _dt(a), _st()), "acai_gelu_fwd")
+    return h
+
+
+def gelu_bwd(a, dh):
+    _chk(a, "a"), _chk(dh, "dh")
+    assert a.is_contiguous() and dh.is_contiguous() and a.dtype == dh.dtype and a.shape == dh.shape
+    da = torch.empty_like(a)
+    _lib.check(_lib.lib().acai_gelu_bwd(a.data_ptr(), dh.data_ptr(), da.data_ptr(), a.numel(), _dt(a), _st()), "acai_gelu_bwd")
+    return da
+
+
+def colsum(x):
+    _chk(x, "x")
+    assert x.dim() == 2
+    out = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().acai_colsum(x.data_ptr(), x.stride(0), out.data_ptr(), x.shape[0], x.shape[1], _dt(x), _st()), "acai_colsum")
+    return out
+
+
+def scatter_add_rows(src, idx, dst):
+    _chk(src, "src", torch.float32), _chk(idx, "idx", torch.int32), _chk(dst, "dst", torch.float32)
+    assert src.is_contiguous() and dst.is_contiguous() and src.shape[1] == dst.shape[1] and idx.numel() == src.shape[0]
+    _lib.check(_lib.lib().acai_scatter_add_rows(src.data_ptr(), idx.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1], _st()), "acai_scatter_add_rows")
+    return dst
+
+
+def mae_loss(pred, target, mask, count, want_grad):
+    """pred/target [R,D] fp32, mask [R] uint8; returns (loss scalar tensor, dpred or None) for loss = masked mean."""
+    _chk(pred, "pred", torch.float32), _chk(target, "target", torch.float32), _chk(mask, "mask", torch.uint8)
+    assert pred.is_contiguous() and target.is_contiguous() and pred.shape == target.shape and mask.numel() == pred.shape[0]
+    loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
+    dpred = torch.empty_like(pred) if want_grad else None
+    _lib.check(_lib.lib().acai_mae_loss(pred.data_ptr(), target.data_ptr(), mask.data_ptr(), 1.0 / float(count), loss.data_ptr(), _p(dpred),
+                                        pred.shape[0], pred.shape[1], _st()), "acai_mae_loss")
+    return loss[0], dpred
+
+
+def ce_loss(logits, target, ignore_index, count, want_grad):
+    _chk(logits, "logits", torch.float32), _chk(target, "target", torch.int64)
+    assert logits.dim() == 2 and target.numel() == logits.shape[0] and target.is_contiguous()
+    loss = torch.zeros(1, dtype=torch.float32, device=logits.device)
+    dl = torch.empty(logits.shape, dtype=torch.float32, device=logits.device) if want_grad else None
+    _lib.check(_lib.lib().acai_ce_loss(logits.data_ptr(), logits.stride(0), target.data_ptr(), int(ignore_index), 1.0 / float(count), loss.data_ptr(),
+                                       _p(dl), logits.shape[0], logits.shape[1], _st()), "acai_ce_loss")
+    return loss[0], dl
 
 
 class Graph:

@@ -1,0 +1,485 @@
+"""Differentiable (training) execution of the hot path: torch.autograd.Function wrappers around the HIP kernels.
+
+Forward and backward arithmetic both run in the HIP library (GEMM NT/NN/TN, varlen attention fwd/bwd, LayerNorm fwd/bwd,
+GELU, row gather / scatter-add, the two losses); torch.autograd only records the graph and accumulates `.grad`.
+Everything works on packed token streams; the padded `(B, L, E)` views the reference API hands around are produced by a
+differentiable row gather (`pad_rows`).
+
+Step semantics reproduced: MAE pre-training runs fp32 outside autocast
+(acai_omr/train/pre_train.py:54-62); the teacher-forced step runs its forward under autocast(bfloat16)
+(acai_omr/train/omr_teacher_force_train.py:113-120) - precision follows `torch.is_autocast_enabled("cuda")` exactly as in
+the inference path.  Dropout > 0 in train mode is not built yet (the parity configs use p = 0) and raises.
+"""
+import torch
+from torch.autograd import Function
+
+from .. import engine as EG
+from .. import ops
+from ..models.kv_caching import _wc
+
+
+def _prec():
+    return "bf16" if torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16 else "fp32"
+
+
+def _cdt(prec):
+    return torch.bfloat16 if prec == "bf16" else torch.float32
+
+
+def _check_dropout(module):
+    if module.training:
+        for m in module.modules():
+            p = getattr(m, "p", None) if isinstance(m, torch.nn.Dropout) else getattr(m, "dropout", None) if isinstance(m, torch.nn.MultiheadAttention) else None
+            if isinstance(p, float) and p > 0.0:
+                raise NotImplementedError("acai_omr_amd: dropout > 0 in train mode is not built in the HIP training path yet; construct the model "
+                                          "with dropout 0.0 (as the parity configs do) or call .eval()")
+
+
+# ---- autograd Functions ---------------------------------------------------------------------------------------------------
+class LinearFn(Function):
+    """y = x @ W^T + b (+ residual).  x in the compute dtype; y fp32 when a residual is added, else compute dtype (or fp32 on request)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, residual, prec, wc, out_fp32):
+        bf = prec == "bf16"
+        Wc, bc = wc.w(W, prec), wc.b(b, prec)
+        out_dtype = torch.float32 if (residual is not None or out_fp32 or not bf) else torch.bfloat16
+        y = ops.gemm_nt(x, Wc, bc, residual=residual, out_dtype=out_dtype, round_bf16=bf)
+        ctx.save_for_backward(x, W)
+        ctx.prec, ctx.wc, ctx.has_res, ctx.has_bias = prec, wc, residual is not None, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        prec, bf = ctx.prec, ctx.prec == "bf16"
+        dy = dy.contiguous()
+        dres = dy if ctx.has_res else None
+        dyc = dy
+        if bf and dy.dtype != torch.bfloat16:
+            dyc = ops.cast_bf16(dy)
+        elif not bf and dy.dtype != torch.float32:
+            dyc = dy.float()
+        Wc = ctx.wc.w(W, prec)
+        dx = ops.gemm(dyc, Wc, trans_w=True, out_dtype=x.dtype) if ctx.needs_input_grad[0] else None
+        dW = ops.gemm(dyc, x, trans_a=True, trans_w=True, out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        db = ops.colsum(dyc) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dW, db, dres, None, None, None
+
+
+class SelfAttnFn(Function):
+    """Packed self attention on a fused qkv tensor [M, 3E] -> [M, E]."""
+
+    @staticmethod
+    def forward(ctx, qkv, cu, H, dh, max_len, causal):
+        E = H * dh
+        M = qkv.shape[0]
+        lse = torch.empty(H * M, dtype=torch.float32, device=qkv.device)
+        out = ops.attn_varlen(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], cu, cu, H, dh, max_len, causal=causal, lse=lse)
+        ctx.save_for_backward(qkv, out, lse, cu)
+        ctx.cfg = (H, dh, max_len, causal)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse, cu = ctx.saved_tensors
+        H, dh, max_len, causal = ctx.cfg
+        E = H * dh
+        dqkv = torch.empty_like(qkv)
+        dout = dout.contiguous().to(qkv.dtype)
+        ops.attn_varlen_bwd(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], out, dout, lse, cu, cu, H, dh, max_len, max_len, causal,
+                            dqkv[:, :E], dqkv[:, E:2 * E], dqkv[:, 2 * E:])
+        return dqkv, None, None, None, None, None
+
+
+class CrossAttnFn(Function):
+    """Packed cross attention: q [Mq, E], kv [Mk, 2E] -> [Mq, E]."""
+
+    @staticmethod
+    def forward(ctx, q, kv, cu_q, cu_k, H, dh, max_q, max_k):
+        E = H * dh
+        lse = torch.empty(H * q.shape[0], dtype=torch.float32, device=q.device)
+        out = ops.attn_varlen(q, kv[:, :E], kv[:, E:], cu_q, cu_k, H, dh, max_q, lse=lse)
+        ctx.save_for_backward(q, kv, out, lse, cu_q, cu_k)
+        ctx.cfg = (H, dh, max_q, max_k)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, out, lse, cu_q, cu_k = ctx.saved_tensors
+        H, dh, max_q, max_k = ctx.cfg
+        E = H * dh
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        ops.attn_varlen_bwd(q, kv[:, :E], kv[:, E:], out, dout.contiguous().to(q.dtype), lse, cu_q, cu_k, H, dh, max_q, max_k, False,
+                            dq, dkv[:, :E], dkv[:, E:])
+        return dq, dkv, None, None, None, None, None, None
+
+
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        y = ops.layernorm(x, w.detach(), b.detach(), eps)[0]
+        ctx.save_for_backward(x, w)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx, dw, db = ops.layernorm_bwd(x, w.detach(), dy.contiguous().float(), ctx.eps)
+        return dx, dw, db, None
+
+
+class CastBf16Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.cast_bf16(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy.float()
+
+
+class GeluFn(Function):
+    @staticmethod
+    def forward(ctx, a):
+        ctx.save_for_backward(a)
+        return ops.gelu_fwd(a)
+
+    @staticmethod
+    def backward(ctx, dh):
+        (a,) = ctx.saved_tensors
+        return ops.gelu_bwd(a, dh.contiguous().to(a.dtype))
+
+
+class GatherRowsFn(Function):
+    """out[i] = table[idx[i]] (+ add[i]); backward scatter-adds into the table."""
+
+    @staticmethod
+    def forward(ctx, table, idx, add):
+        ctx.save_for_backward(idx)
+        ctx.shape = table.shape
+        ctx.has_add = add is not None
+        return ops.gather_rows(table.contiguous(), idx, add)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        dt = None
+        if ctx.needs_input_grad[0]:
+            dt = ops.scatter_add_rows(dy, idx, torch.zeros(ctx.shape, dtype=torch.float32, device=dy.device))
+        return dt, None, (dy if ctx.has_add else None)
+
+
+def pad_rows(packed, lens, fill_row=None):
+    """Differentiable EG.pad_rows: (M,E) -> (B, Lmax, E) and mask; gradient of padded rows is dropped."""
+    B, Lm, E, M = len(lens), max(lens), packed.shape[1], packed.shape[0]
+    dev = packed.device
+    fill = torch.zeros(1, E, device=dev) if fill_row is None else fill_row.detach().reshape(1, E).float()
+    table = torch.cat([packed, fill], 0)
+    idx = torch.full((B, Lm), M, dtype=torch.int32)
+    mask = torch.ones(B, Lm, dtype=torch.bool)
+    o = 0
+    for b, l in enumerate(lens):
+        idx[b, :l] = torch.arange(o, o + l, dtype=torch.int32)
+        mask[b, :l] = False
+        o += l
+    out = GatherRowsFn.apply(table, idx.reshape(-1).to(dev), None)
+    return out.view(B, Lm, E), mask.to(dev)
+
+
+def unpad_rows(padded, mask):
+    B, Lm, E = padded.shape
+    lens = [Lm] * B if mask is None else (~mask).sum(dim=1).tolist()
+    idx = torch.cat([torch.arange(b * Lm, b * Lm + l, dtype=torch.int32) for b, l in enumerate(lens)]).to(padded.device)
+    return GatherRowsFn.apply(padded.reshape(B * Lm, E).float(), idx, None), lens
+
+
+# ---- building blocks ---------------------------------------------------------------------------------------------------------
+def _lin(x32, lin_w, lin_b, prec, wc, residual=None, out_fp32=False):
+    """nn.Linear on an fp32 activation: casts to the compute dtype (autocast's input cast) and applies LinearFn."""
+    x = CastBf16Fn.apply(x32) if (prec == "bf16" and x32.dtype != torch.bfloat16) else x32
+    return LinearFn.apply(x, lin_w, lin_b, residual, prec, wc, out_fp32)
+
+
+def encoder_stack(stack, x32, cu, max_len, H, prec, wc):
+    E = x32.shape[1]
+    dh = E // H
+    for layer in stack.layers:
+        sa = layer.self_attn
+        qkv = _lin(x32, sa.in_proj_weight, sa.in_proj_bias, prec, wc)
+        attn = SelfAttnFn.apply(qkv, cu, H, dh, max_len, False)
+        y = LinearFn.apply(attn, sa.out_proj.weight, sa.out_proj.bias, x32, prec, wc, True)
+        x32 = LayerNormFn.apply(y, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
+        a = _lin(x32, layer.linear1.weight, layer.linear1.bias, prec, wc)
+        h = GeluFn.apply(a)
+        y = LinearFn.apply(h, layer.linear2.weight, layer.linear2.bias, x32, prec, wc, True)
+        x32 = LayerNormFn.apply(y, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
+    if stack.norm is not None:
+        x32 = LayerNormFn.apply(x32, stack.norm.weight, stack.norm.bias, stack.norm.eps)
+    return x32
+
+
+def _patches(enc, imgs, prec, select=None):
+    """Patchify every image into one packed [M, P*P] tensor in the compute dtype (no gradient: inputs are data)."""
+    P = enc.patch_size
+    dims = [enc._grid(t) for t in imgs]
+    lens = [h * w for h, w in dims]
+    dev = enc._device()
+    with torch.no_grad():
+        patches = torch.empty(sum(lens), P * P, dtype=torch.float32, device=dev)
+        r0 = 0
+        for t in imgs:
+            r0 += ops.patchify(t, P, patches, r0)
+        if select is not None:
+            o, rows = 0, []
+            for l, s in zip(lens, select):
+                rows.append(s.to(dev).to(torch.int32) + o)
+                o += l
+            patches = ops.gather_rows(patches, torch.cat(rows).contiguous())
+        if prec == "bf16":
+            patches = ops.cast_bf16(patches)
+    return patches, dims, lens
+
+
+def _pe_rows(enc, table_param, dims, select=None):
+    """Differentiable pos_embedding[:h_p,:w_p] rows (optionally a subset per image) of every image, packed."""
+    dev, E = table_param.device, table_param.shape[-1]
+    Wm = table_param.shape[1]
+    idx = []
+    for i, (h_p, w_p) in enumerate(dims):
+        if h_p > table_param.shape[0] or w_p > Wm:
+            raise NotImplementedError("PE interpolation in the training path is not built (inference path only)")
+        rows = (torch.arange(h_p, dtype=torch.int32).unsqueeze(1) * Wm + torch.arange(w_p, dtype=torch.int32).unsqueeze(0)).reshape(-1)
+        if select is not None:
+            rows = rows[select[i].cpu()]
+        idx.append(rows)
+    return GatherRowsFn.apply(table_param.reshape(-1, E), torch.cat(idx).to(dev), None)
+
+
+def encoder_forward_packed(enc, x):
+    """Training-path Encoder.forward_packed: returns (x32 packed, None, lens) with autograd history."""
+    _check_dropout(enc)
+    from ..models.models import _as_image_list
+    prec, wc = _prec(), _wc(enc)
+    imgs = _as_image_list(x, enc._device())
+    patches, dims, lens = _patches(enc, imgs, prec)
+    pe = _pe_rows(enc, enc.pos_embedding, dims)
+    x32 = LinearFn.apply(patches, enc.projection.weight, enc.projection.bias, pe, prec, wc, True)
+    cu = EG.cu_from_lens(lens, x32.device)
+    for st in enc._stacks():
+        x32 = encoder_stack(st, x32, cu, max(lens), enc._num_heads(), prec, wc)
+    return x32, None, lens
+
+
+def head_forward(head, x):
+    _check_dropout(head)
+    prec, wc = _prec(), _wc(head)
+    shp = x.shape
+    x2 = x.reshape(-1, shp[-1]).float()
+    a = _lin(x2, head[0].weight, head[0].bias, prec, wc)
+    h = GeluFn.apply(a)
+    y = LinearFn.apply(h, head[3].weight, head[3].bias, None, prec, wc, False)
+    return y.view(*shp[:-1], y.shape[-1])
+
+
+# ---- MAE (models.py:100-288) -------------------------------------------------------------------------------------------------
+def _mae_prepare(mae, x, noises):
+    from ..models.models import _as_image_list
+    enc = mae.encoder
+    imgs = _as_image_list(x, enc._device())
+    dims = [enc._grid(t) for t in imgs]
+    keep, restore, smask, kept = [], [], [], []
+    for i, (h, w) in enumerate(dims):
+        n = h * w
+        noise = None if noises is None else noises[i].to(enc._device())
+        ids_keep, ids_restore, seq_mask, k = enc.mask_ids(n, enc._device(), noise)
+        keep.append(ids_keep)
+        restore.append(ids_restore)
+        smask.append(seq_mask)
+        kept.append(k)
+    return imgs, dims, keep, restore, smask, kept
+
+
+def _mae_encode(mae, imgs, dims, keep, kept, prec):
+    enc = mae.encoder
+    wc = _wc(enc)
+    patches, _, _ = _patches(enc, imgs, prec, select=keep)
+    pe = _pe_rows(enc, enc.pos_embedding, dims, select=keep)
+    x32 = LinearFn.apply(patches, enc.projection.weight, enc.projection.bias, pe, prec, wc, True)
+    cu = EG.cu_from_lens(kept, x32.device)
+    return encoder_stack(enc.encoder_blocks, x32, cu, max(kept), enc._num_heads(), prec, wc)
+
+
+def mae_encoder_forward(enc, x, noises=None):
+    """MAEEncoder.forward (models.py:176-180) with the reference's return tuple (padded latent, masks, lens, jagged tensors)."""
+    _check_dropout(enc)
+
+    class _Shim:
+        encoder = enc
+    imgs, dims, keep, restore, smask, kept = _mae_prepare(_Shim, x, noises)
+    lat = _mae_encode(_Shim, imgs, dims, keep, kept, _prec())
+    lens = [h * w for h, w in dims]
+    padded, _ = pad_rows(lat, kept)
+    dec_mask = enc.create_attention_mask(lens, max(lens)).to(lat.device)
+    seq_masks = torch.nested.as_nested_tensor(smask, layout=torch.jagged)
+    ids_restore = torch.nested.as_nested_tensor(restore, layout=torch.jagged)
+    return padded, dec_mask, kept, lens, seq_masks, ids_restore, dims
+
+
+def mae_decoder_forward(dec, x, attention_mask):
+    _check_dropout(dec)
+    packed, lens = unpad_rows(x, attention_mask)
+    cu = EG.cu_from_lens(lens, packed.device)
+    H = dec.decoder_blocks.layers[0].self_attn.num_heads
+    y = encoder_stack(dec.decoder_blocks, packed, cu, max(lens), H, _prec(), _wc(dec))
+    return pad_rows(y, lens)[0]
+
+
+def mae_forward(mae, batch, noises=None, packed=False):
+    """MAE.forward (models.py:249-269).  Returns (pred, loss_mask, target) padded as the reference does, or packed
+    (pred [sum N, P^2], loss_mask [sum N] bool, target, lens) when packed=True."""
+    _check_dropout(mae)
+    xs, ys = zip(*batch)
+    prec = _prec()
+    imgs, dims, keep, restore, smask, kept = _mae_prepare(mae, list(xs), noises)
+    lens = [h * w for h, w in dims]
+    dev = mae.decoder_pos_embedding.device
+    lat = _mae_encode(mae, imgs, dims, keep, kept, prec)
+    wc = _wc(mae)
+    lat = _lin(lat, mae.decoder_embed.weight, mae.decoder_embed.bias, prec, wc, out_fp32=True)
+    # prepare_for_decoder (models.py:219-241): [kept tokens | mask tokens] unshuffled by ids_restore, + decoder PE
+    D = mae.decoder_hidden_dim
+    table = torch.cat([lat, mae.mask_token.reshape(1, D)], 0)
+    Mk = lat.shape[0]
+    idx, o = [], 0
+    for k, n, r in zip(kept, lens, restore):
+        r = r.cpu()
+        idx.append(torch.where(r < k, r + o, torch.full_like(r, Mk)).to(torch.int32))
+        o += k
+    dpe = _pe_rows(mae.encoder, mae.decoder_pos_embedding, dims)
+    x32 = GatherRowsFn.apply(table, torch.cat(idx).to(dev), dpe)
+    cu = EG.cu_from_lens(lens, dev)
+    H = mae.decoder.decoder_blocks.layers[0].self_attn.num_heads
+    x32 = encoder_stack(mae.decoder.decoder_blocks, x32, cu, max(lens), H, prec, _wc(mae.decoder))
+    pred = _lin(x32, mae.decoder_unembed.weight, mae.decoder_unembed.bias, prec, wc, out_fp32=True)
+    # targets and loss mask (no gradient)
+    from ..models.models import _as_image_list
+    with torch.no_grad():
+        timgs = _as_image_list(list(ys), dev)
+        target = _patches(mae.encoder, timgs, "fp32")[0]
+        loss_mask = torch.cat([m.to(dev).bool() for m in smask])
+    if packed:
+        return pred, loss_mask, target, lens
+    ppred, pmask = pad_rows(pred, lens)
+    ptarget = EG.pad_rows(target, lens)[0]
+    plm = torch.zeros(len(lens), max(lens), dtype=torch.bool, device=dev)
+    o = 0
+    for b, l in enumerate(lens):
+        plm[b, :l] = loss_mask[o:o + l]
+        o += l
+    return ppred, plm, ptarget
+
+
+class MaeLossFn(Function):
+    @staticmethod
+    def forward(ctx, pred, mask_u8, target, count):
+        loss, dpred = ops.mae_loss(pred, target, mask_u8, count, want_grad=True)
+        ctx.save_for_backward(dpred)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return dpred * g, None, None, None
+
+
+def mae_loss(pred, loss_mask, target):
+    """MAELoss.forward (models.py:273-288) on padded (N,L,D) or packed (M,D) tensors."""
+    D = pred.shape[-1]
+    p2 = pred.reshape(-1, D).float().contiguous()
+    t2 = target.reshape(-1, D).float().contiguous()
+    m = loss_mask.reshape(-1)
+    count = float(m.sum().item())
+    return MaeLossFn.apply(p2, m.to(torch.uint8).contiguous(), t2, count)
+
+
+class CeLossFn(Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index, count):
+        loss, dl = ops.ce_loss(logits, target, ignore_index, count, want_grad=True)
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None, None, None
+
+
+def ce_loss(pred, target_seqs, pad_idx):
+    """OMRCELoss.forward (models.py:790-796): mean CE over non-pad targets."""
+    V = pred.shape[-1]
+    lg = pred.reshape(-1, V).float().contiguous()
+    tg = target_seqs.reshape(-1).to(device=lg.device, dtype=torch.int64).contiguous()
+    count = float((tg != pad_idx).sum().item())
+    return CeLossFn.apply(lg, tg, pad_idx, count)
+
+
+# ---- teacher-forced decoder (models.py:445-483) ---------------------------------------------------------------------------------
+def decoder_forward(dec, input_seqs, img_latent, lmx_attention_mask, latent_attention_mask, token_idxs_input=True):
+    _check_dropout(dec)
+    prec, wc = _prec(), _wc(dec)
+    bf = prec == "bf16"
+    dev, E, H = dec.pos_embedding.device, dec.hidden_dim, dec.num_heads
+    dh = E // H
+    B, T = input_seqs.shape[0], input_seqs.shape[1]
+    lens_t = [T] * B if lmx_attention_mask is None else (~lmx_attention_mask).sum(dim=1).tolist()
+    mem32, lens_s = unpad_rows(img_latent.to(dev), latent_attention_mask)
+    pos_idx = torch.cat([torch.arange(t, dtype=torch.int32) for t in lens_t]).to(dev)
+    pos = GatherRowsFn.apply(dec.pos_embedding, pos_idx, None)
+    if token_idxs_input:
+        tok = torch.cat([input_seqs[b, :l] for b, l in enumerate(lens_t)]).to(device=dev, dtype=torch.int32).contiguous()
+        x32 = GatherRowsFn.apply(dec.vocab_embedding.weight, tok, pos)
+    else:
+        idx = torch.cat([torch.arange(b * T, b * T + l, dtype=torch.int32) for b, l in enumerate(lens_t)]).to(dev)
+        x32 = GatherRowsFn.apply(input_seqs.reshape(B * T, E).float(), idx, pos)
+    cu_t, cu_s = EG.cu_from_lens(lens_t, dev), EG.cu_from_lens(lens_s, dev)
+    memc = CastBf16Fn.apply(mem32) if bf else mem32
+    mt, ms = max(lens_t), max(lens_s)
+    for ly in dec.decoder_blocks.layers:
+        sa, ca = ly.self_attn, ly.multihead_attn
+        qkv = _lin(x32, sa.in_proj_weight, sa.in_proj_bias, prec, wc)
+        a = SelfAttnFn.apply(qkv, cu_t, H, dh, mt, True)
+        y = LinearFn.apply(a, sa.out_proj.weight, sa.out_proj.bias, x32, prec, wc, True)
+        x32 = LayerNormFn.apply(y, ly.norm1.weight, ly.norm1.bias, ly.norm1.eps)
+        xc = CastBf16Fn.apply(x32) if bf else x32
+        q = LinearFn.apply(xc, ca.in_proj_weight[:E], ca.in_proj_bias[:E], None, prec, _SliceCache(wc, ca, 0, E), False)
+        kv = LinearFn.apply(memc, ca.in_proj_weight[E:], ca.in_proj_bias[E:], None, prec, _SliceCache(wc, ca, E, 3 * E), False)
+        a = CrossAttnFn.apply(q, kv, cu_t, cu_s, H, dh, mt, ms)
+        y = LinearFn.apply(a, ca.out_proj.weight, ca.out_proj.bias, x32, prec, wc, True)
+        x32 = LayerNormFn.apply(y, ly.norm2.weight, ly.norm2.bias, ly.norm2.eps)
+        a1 = _lin(x32, ly.linear1.weight, ly.linear1.bias, prec, wc)
+        h = GeluFn.apply(a1)
+        y = LinearFn.apply(h, ly.linear2.weight, ly.linear2.bias, x32, prec, wc, True)
+        x32 = LayerNormFn.apply(y, ly.norm3.weight, ly.norm3.bias, ly.norm3.eps)
+    nrm = dec.decoder_blocks.norm
+    x32 = LayerNormFn.apply(x32, nrm.weight, nrm.bias, nrm.eps)
+    logits = _lin(x32, dec.unembed.weight, dec.unembed.bias, prec, wc, out_fp32=True)
+    out = pad_rows(logits, lens_t)[0]
+    return out.to(torch.bfloat16) if bf else out
+
+
+class _SliceCache:
+    """WeightCache view for a row slice of a fused in_proj parameter (autograd hands LinearFn the sliced tensor, the cache
+    is keyed on the full parameter)."""
+
+    def __init__(self, wc, attn, r0, r1):
+        self.wc, self.attn, self.r0, self.r1 = wc, attn, r0, r1
+
+    def w(self, _p, prec):
+        return self.wc.w(self.attn.in_proj_weight, prec)[self.r0:self.r1]
+
+    def b(self, _p, prec):
+        return None if _p is None else self.wc.b(self.attn.in_proj_bias, prec)[self.r0:self.r1]

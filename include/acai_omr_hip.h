@@ -45,6 +45,13 @@ int acai_layernorm_fwd(const float *x, const float *w, const float *b, float eps
 int acai_gemm_nt(const void *A, int lda, const void *W, int ldw, const float *bias, const float *residual, int ldr,
                  void *C, int ldc, int M, int N, int K, int in_dtype, int out_dtype, int flags, void *stream);
 
+/* The same contraction with either operand stored reduction-major, for the backward of nn.Linear (autograd of M:29,57,...):
+ *   dX = dY . W   -> acai_gemm(dY, ldy, 0,  W, ldw, 1, ...)  (M = rows, N = in_features, K = out_features)
+ *   dW = dY^T . X -> acai_gemm(dY, ldy, 1,  X, ldx, 1, ...)  (M = out_features, N = in_features, K = rows)
+ * trans_a: A stored [K][M]; trans_w: W stored [K][N].  residual may alias C (gradient accumulation). */
+int acai_gemm(const void *A, int lda, int trans_a, const void *W, int ldw, int trans_w, const float *bias, const float *residual, int ldr,
+              void *C, int ldc, int M, int N, int K, int in_dtype, int out_dtype, int flags, void *stream);
+
 /* MemoryCache.cache_memory_keys_and_vals (K:235-253): KV = mem . W_kv^T + b_kv with W_kv = rows E..3E of the
  * cross-attention in_proj; written head-major and ragged for the decode kernels:
  * k_out[seq_off[b] + (h*len[b] + s)*dhp + d], same for v_out; row_seq/row_pos give (b, s) of each memory row. */
@@ -66,10 +73,38 @@ int acai_cast_f32_bf16(const float *x, void *y, int64_t n, void *stream);
 /* F.scaled_dot_product_attention on packed ragged streams (torch nn.MultiheadAttention inside
  * nn.TransformerEncoderLayer M:30-34,186-190 and nn.TransformerDecoderLayer M:422-426).
  * q row i of sequence b is q + (cu_q[b]+i)*ldq + h*dh; same for k, v (cu_k) and out.
- * causal != 0 applies the triu(diagonal=1) mask of M:468.  dh <= 64. */
+ * causal != 0 applies the triu(diagonal=1) mask of M:468.  dh <= 64.
+ * lse (optional, [H][total_q] fp32): log2-domain log-sum-exp of the scaled scores, saved for acai_attn_varlen_bwd. */
 int acai_attn_varlen_fwd(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, void *out, int ldo,
                          const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int causal,
-                         int dtype, void *stream);
+                         int dtype, float *lse, int total_q, void *stream);
+
+/* Backward of acai_attn_varlen_fwd (autograd of the same SDPA; training loops pre_train.py:59, omr_teacher_force_train.py:118).
+ * o / lse are the forward's outputs, dout the incoming gradient; dq/dk/dv take the layout of q/k/v (own row strides).
+ * delta: workspace [H][total_q] floats.  Deterministic (no atomics): S and P are recomputed per kernel. */
+int acai_attn_varlen_bwd(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, const void *o, int ldo,
+                         const void *dout, int lddo, void *dq, int lddq, void *dk, int lddk, void *dv, int lddv, const float *lse,
+                         float *delta, const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int max_k,
+                         int total_q, int causal, int dtype, void *stream);
+
+/* Backward of nn.LayerNorm: dx (fp32) from x, w, dy; dw/db (may be NULL) are ACCUMULATED with fp32 atomics (zero or seed them);
+ * stats: workspace [rows][2]. */
+int acai_layernorm_bwd(const float *x, const float *w, const float *dy, float eps, float *dx, float *dw, float *db, float *stats,
+                       int rows, int dim, void *stream);
+/* exact-erf GELU as a stand-alone pass (training keeps the pre-activation) and its derivative: da = dh * gelu'(a). */
+int acai_gelu_fwd(const void *a, void *h, int64_t n, int dtype, void *stream);
+int acai_gelu_bwd(const void *a, const void *dh, void *da, int64_t n, int dtype, void *stream);
+/* out[c] += sum_r x[r,c] (bias gradients); out fp32, accumulated with atomics. */
+int acai_colsum(const void *x, int ld, float *out, int rows, int cols, int dtype, void *stream);
+/* dst[idx[r],:] += src[r,:] (gradients of nn.Embedding M:460, pos_embedding slices M:50, MAE index_select M:114,229). */
+int acai_scatter_add_rows(const float *src, const int32_t *idx, float *dst, int rows, int dim, void *stream);
+/* MAELoss (M:271-288) forward + backward on packed rows: *loss += sum_r mask_r * mean_d((pred - that)^2) * inv_count,
+ * dpred (may be NULL) = d loss / d pred; that = (target - mean) / sqrt(var_unbiased + 1e-6). */
+int acai_mae_loss(const float *pred, const float *target, const unsigned char *mask, float inv_count, float *loss, float *dpred,
+                  int rows, int dim, void *stream);
+/* OMRCELoss (M:784-796) forward + backward: mean cross entropy over rows whose target != ignore_index. */
+int acai_ce_loss(const float *logits, int ld, const int64_t *target, int ignore_index, float inv_count, float *loss, float *dlogits,
+                 int rows, int V, void *stream);
 
 /* ---- KV-cached greedy decode (K:190-223, K:292-302, M:518-528, M:575-583) ------------------------------- */
 typedef struct {

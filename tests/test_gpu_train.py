@@ -1,0 +1,185 @@
+"""Training-path parity on the GPU: forward + loss + gradients of the HIP autograd path against the golden vectors the
+imported reference produced (tests/golden/{mae_*,tf_*}.pt), plus kernel-level checks of the backward kernels against
+torch autograd on the CPU."""
+import math
+
+import pytest
+import torch
+
+from conftest import VOCAB, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from acai_omr_amd import _lib
+    _lib.lib()
+    return "cuda"
+
+
+def md(a, b):
+    return float((a.detach().float().cpu() - b.detach().float().cpu()).abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (128, 136, 64), (37, 19, 10), (513, 768, 256)])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_gemm_transposed_variants(dev, M, N, K, dtype):
+    from acai_omr_amd import ops
+    g = torch.Generator().manual_seed(M * N + K)
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    if dtype == "bf16":
+        a, w = a.to(tdt).float(), w.to(tdt).float()
+    ref = a.double() @ w.double().t()
+    tol = 1e-4 if dtype == "fp32" else 1e-3
+    ad, wd = a.to(dev).to(tdt), w.to(dev).to(tdt)
+    for ta in (False, True):
+        for tw in (False, True):
+            A = ad.t().contiguous() if ta else ad
+            W = wd.t().contiguous() if tw else wd
+            y = ops.gemm(A, W, trans_a=ta, trans_w=tw)
+            assert (y.cpu().double() - ref).abs().max() < tol, (ta, tw)
+
+
+@pytest.mark.parametrize("H,dh,lens_q,lens_k,causal", [
+    (2, 64, [8, 32, 200], None, False),
+    (3, 32, [130, 1, 77], None, False),
+    (2, 16, [65, 64], None, True),
+    (1, 6, [5, 9, 3], None, False),
+    (4, 12, [7, 12], [20, 13], False),
+    (2, 64, [300], None, True),
+])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_attn_backward(dev, H, dh, lens_q, lens_k, causal, dtype):
+    from acai_omr_amd import engine, ops
+    lens_k = lens_k or lens_q
+    g = torch.Generator().manual_seed(H * dh + sum(lens_q) + 7)
+    E = H * dh
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    q = torch.randn(sum(lens_q), E, generator=g).to(tdt).float()
+    k = torch.randn(sum(lens_k), E, generator=g).to(tdt).float()
+    v = torch.randn(sum(lens_k), E, generator=g).to(tdt).float()
+    dout = torch.randn(sum(lens_q), E, generator=g).to(tdt).float()
+    # reference: torch autograd in float64
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    out = torch.zeros(sum(lens_q), E, dtype=torch.float64)
+    oq = ok = 0
+    outs = []
+    for lq, lk in zip(lens_q, lens_k):
+        for h in range(H):
+            sl = slice(h * dh, (h + 1) * dh)
+            s = qr[oq:oq + lq, sl] @ kr[ok:ok + lk, sl].t() / math.sqrt(dh)
+            if causal:
+                s = s.masked_fill(~torch.ones(lq, lk, dtype=torch.bool).tril(), float("-inf"))
+            outs.append((oq, lq, sl, torch.softmax(s, -1) @ vr[ok:ok + lk, sl]))
+        oq += lq
+        ok += lk
+    loss = sum((o * dout[a:a + l, sl].double()).sum() for a, l, sl, o in outs)
+    loss.backward()
+    qd, kd, vd, dd = (t.to(dev).to(tdt) for t in (q, k, v, dout))
+    cu_q, cu_k = engine.cu_from_lens(lens_q, dev), engine.cu_from_lens(lens_k, dev)
+    lse = torch.empty(H * sum(lens_q), device=dev)
+    o = ops.attn_varlen(qd, kd, vd, cu_q, cu_k, H, dh, max(lens_q), causal=causal, lse=lse)
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    ops.attn_varlen_bwd(qd, kd, vd, o, dd, lse, cu_q, cu_k, H, dh, max(lens_q), max(lens_k), causal, dq, dk, dv)
+    tol = 3e-5 if dtype == "fp32" else 6e-2
+    for name, got, ref in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        err = (got.cpu().double() - ref).abs().max() / max(1.0, float(ref.abs().max()))
+        assert err < tol, (name, float(err))
+
+
+def test_row_kernels_backward(dev):
+    from acai_omr_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for rows, dim in [(37, 768), (5, 10), (130, 512)]:
+        x = (torch.randn(rows, dim, generator=g) * 2 + 0.5).requires_grad_(True)
+        w, b = torch.randn(dim, generator=g).requires_grad_(True), torch.randn(dim, generator=g).requires_grad_(True)
+        dy = torch.randn(rows, dim, generator=g)
+        torch.nn.functional.layer_norm(x, (dim,), w, b, 1e-5).backward(dy)
+        dx, dw, db = ops.layernorm_bwd(x.detach().to(dev), w.detach().to(dev), dy.to(dev), 1e-5)
+        assert md(dx, x.grad) < 1e-4 and md(dw, w.grad) < 1e-3 and md(db, b.grad) < 1e-3
+    a = torch.randn(1000, generator=g).requires_grad_(True)
+    dh = torch.randn(1000, generator=g)
+    torch.nn.functional.gelu(a).backward(dh)
+    assert md(ops.gelu_fwd(a.detach().to(dev)), torch.nn.functional.gelu(a)) < 1e-6
+    assert md(ops.gelu_bwd(a.detach().to(dev), dh.to(dev)), a.grad) < 1e-5
+    x = torch.randn(5000, 70, generator=g)
+    assert md(ops.colsum(x.to(dev)), x.sum(0)) < 2e-3
+    src, idx = torch.randn(300, 24, generator=g), torch.randint(0, 17, (300,), generator=g)
+    dst = torch.zeros(17, 24)
+    dst.index_add_(0, idx, src)
+    assert md(ops.scatter_add_rows(src.to(dev), idx.to(torch.int32).to(dev), torch.zeros(17, 24, device=dev)), dst) < 1e-4
+    # MAELoss KAT (reference tests/test_mae.py:169-180) through the HIP loss kernel
+    from acai_omr_amd.models.models import MAELoss, OMRCELoss
+    target = torch.cat([torch.tensor([[1, 1, 1], [2, 2, 2]], dtype=torch.float).unsqueeze(-1).repeat(1, 1, 6),
+                        torch.tensor([[2, 2, 2], [3, 3, 3]], dtype=torch.float).unsqueeze(-1).repeat(1, 1, 6)], dim=-1)
+    pred = torch.tensor([[2, 2, 2], [3, 3, 4]], dtype=torch.float).unsqueeze(-1).repeat(1, 1, 12)
+    lm = torch.tensor([[1, 0, 0], [1, 0, 1]], dtype=torch.float)
+    assert abs(float(MAELoss()(pred.to(dev), lm.to(dev), target.to(dev))) - 10.583329200744629) < 1e-5
+    lg = torch.randn(6, 9, 227, generator=g).requires_grad_(True)
+    tg = torch.randint(0, 227, (6, 9), generator=g)
+    tg[0, 3:] = 1
+    ref = torch.nn.functional.cross_entropy(lg.reshape(-1, 227), tg.reshape(-1), ignore_index=1)
+    ref.backward()
+    lgd = lg.detach().to(dev).requires_grad_(True)
+    loss = OMRCELoss(1)(lgd, tg.to(dev))
+    loss.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 and md(lgd.grad, lg.grad) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["mae_small", "mae_debug_ckpt"])
+def test_mae_forward_loss_grads_vs_reference(dev, name):
+    from acai_omr_amd.models.models import MAE, MAELoss
+    fx = load_golden(name)
+    cfg = fx["cfg"]
+    mae = MAE(cfg["mask_ratio"], cfg["P"], cfg["pe_h"], cfg["pe_w"], encoder_hidden_dim=cfg["enc_dim"], decoder_hidden_dim=cfg["dec_dim"],
+              encoder_kwargs=cfg["enc_kwargs"], decoder_kwargs=cfg["dec_kwargs"])
+    mae.load_state_dict(fx["state_dict"])
+    mae = mae.to(dev).train()
+    batch = list(zip(fx["imgs"], fx["tgts"]))
+    pred, loss_mask, target = mae(batch, noises=fx["noises"])
+    assert torch.equal(loss_mask.cpu(), fx["loss_mask"])
+    assert torch.equal(target.cpu(), fx["target"])
+    valid = ~(torch.arange(fx["pred"].shape[1]).unsqueeze(0) >= torch.tensor([m.numel() for m in fx["noises"]]).unsqueeze(1))
+    assert md(pred.cpu()[valid], fx["pred"][valid]) < 2e-4
+    loss = MAELoss()(pred, loss_mask, target)
+    assert abs(float(loss) - float(fx["loss"])) < 1e-4
+    loss.backward()
+    params = dict(mae.named_parameters())
+    for n, gref in fx["grads"].items():
+        assert md(params[n].grad, gref) < 2e-4 * max(1.0, float(gref.abs().max())), n
+    # gradient confined to the used PE region (reference tests/test_mae.py:182-202)
+    hp = max(t.shape[-2] // cfg["P"] for t in fx["imgs"])
+    wp = max(t.shape[-1] // cfg["P"] for t in fx["imgs"])
+    assert float(mae.encoder.pos_embedding.grad[hp:, :, :].abs().sum()) == 0 and float(mae.encoder.pos_embedding.grad[:, wp:, :].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("name", ["tf_small", "tf_dh64"])
+def test_teacher_forced_train_step_vs_reference(dev, name):
+    from acai_omr_amd.models.models import FineTuneOMREncoder, OMRCELoss, OMRDecoder, TeacherForcedViTOMR
+    fx = load_golden(name)
+    cfg = fx["cfg"]
+    enc = FineTuneOMREncoder(cfg["P"], cfg["pe_h"], cfg["pe_w"], cfg["ft_depth"], num_layers=cfg["enc_layers"], hidden_dim=cfg["enc_dim"],
+                             num_heads=cfg["enc_heads"], mlp_dim=cfg["enc_mlp"], transformer_dropout=0.0)
+    dec = OMRDecoder(cfg["max_len"], VOCAB, num_layers=cfg["dec_layers"], hidden_dim=cfg["dec_dim"], num_heads=cfg["dec_heads"], mlp_dim=cfg["dec_mlp"],
+                     transformer_dropout=0.0)
+    m = TeacherForcedViTOMR(enc, None, dec, transition_head_dim=cfg["head_dim"], transition_head_dropout=0.0)
+    m.load_state_dict(fx["state_dict"])
+    m = m.to(dev).train()
+    pred, tgt = m(list(zip(fx["imgs"], fx["lmx"])))
+    assert torch.equal(tgt.cpu(), fx["target"])
+    valid = fx["target"] != 1
+    assert md(pred.cpu()[valid], fx["pred"][valid]) < 1e-3
+    loss = OMRCELoss(m.decoder.pad_idx)(pred, tgt)
+    assert abs(float(loss) - float(fx["loss"])) < 1e-4
+    loss.backward()
+    params = dict(m.named_parameters())
+    for n, gref in fx["grads"].items():
+        assert md(params[n].grad, gref) < 3e-4 * max(1.0, float(gref.abs().max())), n
+    # dropout > 0 in train mode is refused loudly (not silently ignored)
+    enc2 = FineTuneOMREncoder(cfg["P"], cfg["pe_h"], cfg["pe_w"], 1, num_layers=2, hidden_dim=32, num_heads=2, mlp_dim=64).to(dev).train()
+    with pytest.raises(NotImplementedError):
+        enc2([torch.rand(1, 8, 16)])
