@@ -71,7 +71,13 @@ template <typename T, int EPI, bool FAST, bool TA = false, bool TB = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     constexpr int EPC = 16 / sizeof(T);     // elements per 16-byte chunk
     constexpr int BK = ROWB / sizeof(T);    // k elements per tile
-    __shared__ __attribute__((aligned(16))) unsigned char lds[(BM + BN) * PITCH];
+    // A transposed operand keeps its natural [k][128 rows] image in LDS (16-byte stores, no scatter); its MFMA fragments are
+    // read with ds_read_b64_tr_b16 (bf16: two 4x16 transposing reads per fragment; pitch 320 B puts the 4 k-rows of both
+    // 16-lane groups of a half-wave on disjoint banks) or one ds_read_b32 per K=2 MFMA (fp32).
+    constexpr int PT = sizeof(T) == 2 ? 320 : 528;
+    constexpr int SZA = TA ? BK * PT : BM * PITCH, SZB = TB ? BK * PT : BN * PITCH;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[SZA + SZB];
+    unsigned char *ldsA = lds, *ldsB = lds + SZA;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -118,22 +124,36 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = tid + 256 * i, row = c >> 3, cb = (c & 7) * 16;
-            if constexpr (TA) {
-                union { uint4 v; T e[EPC]; } u;
-                u.v = ra[i];
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) *reinterpret_cast<T *>(lds + ((c % RG) * EPC + e) * PITCH + (c / RG) * sizeof(T)) = u.e[e];
-            } else {
-                *reinterpret_cast<uint4 *>(lds + row * PITCH + cb) = ra[i];
-            }
-            if constexpr (TB) {
-                union { uint4 v; T e[EPC]; } u;
-                u.v = rb[i];
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) *reinterpret_cast<T *>(lds + (BM + (c % RG) * EPC + e) * PITCH + (c / RG) * sizeof(T)) = u.e[e];
-            } else {
-                *reinterpret_cast<uint4 *>(lds + (BM + row) * PITCH + cb) = rb[i];
-            }
+            if constexpr (TA) *reinterpret_cast<uint4 *>(ldsA + (c / RG) * PT + (c % RG) * 16) = ra[i];
+            else *reinterpret_cast<uint4 *>(ldsA + row * PITCH + cb) = ra[i];
+            if constexpr (TB) *reinterpret_cast<uint4 *>(ldsB + (c / RG) * PT + (c % RG) * 16) = rb[i];
+            else *reinterpret_cast<uint4 *>(ldsB + row * PITCH + cb) = rb[i];
+        }
+    };
+
+    // fragment of 32 rows starting at `rowbase`, k-step s (bf16: k = 16s + 8h + j; fp32: k = 8s + 4h + e), from a row-major image
+    // (ds_read_b128) or from a transposed operand's natural image
+    auto frag = [&](const unsigned char *img, bool trans, int rowbase, int s) -> uint4 {
+        if (!trans) return *reinterpret_cast<const uint4 *>(img + (rowbase + lr) * PITCH + s * 32 + lh * 16);
+        if constexpr (sizeof(T) == 2) {
+            typedef __attribute__((ext_vector_type(4))) short s4;
+            typedef __attribute__((address_space(3))) s4 *lds_s4;
+            const int i16 = lane & 15, g1 = (lane >> 4) & 1;  // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3
+            const unsigned char *p0 = img + (16 * s + 8 * lh + (i16 >> 2)) * PT + (rowbase + 16 * g1 + 4 * (i16 & 3)) * 2;
+            const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0));
+            const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0 + 4 * PT));
+            union { s4 v[2]; uint4 u; } r;
+            r.v[0] = lo;
+            r.v[1] = hi;
+            return r.u;
+        } else {
+            const unsigned char *p0 = img + (8 * s + 4 * lh) * PT + (rowbase + lr) * 4;
+            uint4 r;
+            r.x = *reinterpret_cast<const uint32_t *>(p0);
+            r.y = *reinterpret_cast<const uint32_t *>(p0 + PT);
+            r.z = *reinterpret_cast<const uint32_t *>(p0 + 2 * PT);
+            r.w = *reinterpret_cast<const uint32_t *>(p0 + 3 * PT);
+            return r;
         }
     };
 
@@ -147,8 +167,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
             uint4 fa[2], fb[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                fa[i] = *reinterpret_cast<const uint4 *>(lds + (wm * 64 + i * 32 + lr) * PITCH + s * 32 + lh * 16);
-                fb[i] = *reinterpret_cast<const uint4 *>(lds + (BM + wn * 64 + i * 32 + lr) * PITCH + s * 32 + lh * 16);
+                fa[i] = frag(ldsA, TA, wm * 64 + i * 32, s);
+                fb[i] = frag(ldsB, TB, wn * 64 + i * 32, s);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)

@@ -87,6 +87,63 @@ def cpu_baseline(vitomr, lens, steps):
                 sample=f"{steps} greedy decode steps x {B} sequences (S={lens[0]}) after an untimed cross-K/V prefill; CPU oracle in its autocast(bf16) restatement, weights rounded once")
 
 
+def bench_mae(dev, rank, world, dist, batch, height, width, steps, dtype):
+    """Second half of the BASELINE.json metric: MAE images/sec = images / (forward + MAELoss + backward [+ DP gradient
+    all-reduce]) on `batch` synthetic HxW images per GPU, full-size MAE(0.75, 16, 60, 200) (pre_train.py:156-159).
+    The optimizer step is not included (AdamW is stock torch in the reference; a fused one is SURVEY 8f)."""
+    from torch.amp import autocast
+
+    from acai_omr_amd.config import MASK_RATIO, PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH
+    from acai_omr_amd.dist import GradAllReduce, global_mean_scale
+    from acai_omr_amd.models.models import MAE, MAELoss
+    torch.manual_seed(0)
+    mae = MAE(MASK_RATIO, PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH).to(dev).train()
+    ddp = GradAllReduce(mae) if world > 1 else None
+    g = torch.Generator().manual_seed(2000 + rank)
+    imgs = [torch.rand(1, height, width, generator=g).to(dev) for _ in range(batch)]
+    data = list(zip(imgs, imgs))
+    loss_fn = MAELoss()
+
+    def step():
+        if ddp is not None:
+            ddp.zero_grad()
+        else:
+            mae.zero_grad(set_to_none=True)
+        with autocast(device_type="cuda", dtype=torch.bfloat16, enabled=dtype == "bf16"):
+            pred, loss_mask, target, _ = mae.forward_packed(data)
+        loss = loss_fn(pred, loss_mask, target)
+        if ddp is not None:
+            loss = loss * global_mean_scale(float(loss_mask.sum().item()), device=dev)  # mean over the GLOBAL masked count
+        loss.backward()
+        if ddp is not None:
+            ddp.finish()
+        return loss
+
+    step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    flop_img = 2.29e12 * (height * width) / (512 * 2048) if (height, width) == (512, 2048) else None
+    out = dict(images_per_s=world * batch * steps / dt, ms_per_step=dt / steps * 1e3, batch_per_gpu=batch, image=f"{height}x{width}", dtype=dtype,
+               steps=steps, includes="forward + MAELoss + backward" + (" + RCCL gradient all-reduce" if world > 1 else ""), loss=float(loss))
+    if flop_img:
+        out["tflops_algorithmic"] = flop_img * world * batch * steps / dt / 1e12
+    del mae, ddp
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,6 +155,10 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--encoder-dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--mae-batch", type=int, default=32)
+    ap.add_argument("--mae-steps", type=int, default=3)
+    ap.add_argument("--mae-dtype", default="bf16", choices=["fp32", "bf16"])
+    ap.add_argument("--no-mae", action="store_true")
     a = ap.parse_args()
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
@@ -160,6 +221,11 @@ def main():
     tokens = world * a.batch * a.steps
     assert int(eng.step[0].item()) == 1 + a.warmup + a.steps  # every replay advanced the device-side position
 
+    mae_res = None
+    if not a.no_mae:
+        del graph
+        mae_res = bench_mae(dev, rank, world, dist, a.mae_batch, a.height, a.width, a.mae_steps, a.mae_dtype)
+
     out = None
     if rank == 0:
         S = lens[0]
@@ -178,7 +244,7 @@ def main():
                    ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
                    config=dict(workload=f"vitomr_greedy_decode batch {a.batch}/GPU of {a.height}x{a.width} images ({S} patches), decode steps {a.warmup + 1}..{a.warmup + a.steps}",
                                batch_per_gpu=a.batch, memory_len=S, decoder="12 x d1024 h16 mlp4096, V=227", hipgraph=True),
-                   prefill_ms=prefill_s * 1e3, prefill_encoder_dtype=a.encoder_dtype, roofline=roof)
+                   prefill_ms=prefill_s * 1e3, prefill_encoder_dtype=a.encoder_dtype, roofline=roof, mae=mae_res)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vitomr, lens, a.cpu_steps)
         else:
