@@ -3,7 +3,8 @@
 //
 // Flash-style recompute from Q, K, V and the forward's log-sum-exp; no N x N tensor, no atomics, deterministic.
 // Two kernels with the forward's MFMA machinery (32x32 tiles; the lane-owned side sits in registers as the B operand, the
-// streamed side in LDS as the A operand; an accumulator tile is the next MFMA's B operand without touching LDS):
+// streamed side in LDS as the A operand, natural [row][d] image only - the transposed fragments come from ds_read_b64_tr_b16 /
+// ds_read_b32; an accumulator tile is the next MFMA's B operand without touching LDS):
 //   attn_bwd_dq  : workgroup = 128 queries (query on the lane), streams 64-key tiles:
 //                    S^T = K Q^T, P^T = 2^(c S^T - lse),  dP^T = V dO^T,  dS^T = P^T o (dP^T - delta),  dQ^T += K^T dS^T
 //   attn_bwd_dkv : workgroup = 128 keys (key on the lane), streams 64-query tiles:
@@ -60,10 +61,17 @@ __device__ __forceinline__ void mma_rows(f32x16 &acc, const unsigned char *a_row
     }
 }
 
-// acc[d][lane] += A^T(LDS, [d][r] with the 32 contraction rows r contiguous from byte r0) . X, X = a 32x32 accumulator tile whose rows are r
+// acc[c][lane] += tile^T . X: `tile` is a natural [row][col] LDS image (pitch bytes); the 32 contraction rows start at row r0,
+// the 32 output rows are its columns c0..c0+31; X is a 32x32 accumulator tile whose register rows are the contraction rows.
+// bf16: two 4-row x 16-col transposing reads (ds_read_b64_tr_b16) build the A fragment whose element j is contraction row
+// 16 s2 + 8 (j>>2) + 4 lh + (j&3) - the order of X's registers 8 s2 + j.  fp32: one ds_read_b32 per K=2 MFMA.
 template <typename T>
-__device__ __forceinline__ void mma_acc(f32x16 &acc, const unsigned char *at_row, int lh, const f32x16 &x) {
+__device__ __forceinline__ void mma_acc(f32x16 &acc, const unsigned char *tile, int pitch, int r0, int c0, int lane, const f32x16 &x) {
+    const int lr = lane & 31, lh = lane >> 5;
     if constexpr (sizeof(T) == 2) {
+        typedef __attribute__((ext_vector_type(4))) short s4;
+        typedef __attribute__((address_space(3))) s4 *lds_s4;
+        const int i16 = lane & 15, g1 = (lane >> 4) & 1;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             uint4 xf;
@@ -71,30 +79,42 @@ __device__ __forceinline__ void mma_acc(f32x16 &acc, const unsigned char *at_row
             xf.y = pack_bf16(x[8 * s2 + 2], x[8 * s2 + 3]);
             xf.z = pack_bf16(x[8 * s2 + 4], x[8 * s2 + 5]);
             xf.w = pack_bf16(x[8 * s2 + 6], x[8 * s2 + 7]);
-            const unsigned char *p = at_row + (16 * s2 + 4 * lh) * 2;
-            const uint2 lo = *reinterpret_cast<const uint2 *>(p), hi = *reinterpret_cast<const uint2 *>(p + 16);
-            const uint4 af = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, xf), acc, 0, 0, 0);
+            const unsigned char *p = tile + (r0 + 16 * s2 + 4 * lh + (i16 >> 2)) * pitch + (c0 + 16 * g1 + 4 * (i16 & 3)) * 2;
+            union { s4 v[2]; uint4 u; } af;
+            af.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p));
+            af.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p + 8 * pitch));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af.u), __builtin_bit_cast(bf16x8, xf), acc, 0, 0, 0);
         }
     } else {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4 *>(at_row + (8 * g4 + 4 * lh) * 4);
+            const unsigned char *p = tile + (r0 + 8 * g4 + 4 * lh) * pitch + (c0 + lr) * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], x[4 * g4 + e], acc, 0, 0, 0);
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(*reinterpret_cast<const float *>(p + e * pitch), x[4 * g4 + e], acc, 0, 0, 0);
         }
     }
 }
 
-// delta[h][q] = sum_d dO[q, h*dh + d] * O[q, h*dh + d]; one wave per (q, h) pair group
-template <typename T>
+// delta[h][q] = sum_d dO[q, h*dh + d] * O[q, h*dh + d]; one thread per (q, h), 16-byte loads when the head slice allows it
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const T *o, int ldo, const T *dout, int lddo, float *delta, int total_q, int H, int dh) {
+    constexpr int EPC = 16 / sizeof(T);
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= total_q * H) return;
     const int q = idx / H, h = idx - q * H;
     const T *po = o + (size_t)q * ldo + h * dh, *pd = dout + (size_t)q * lddo + h * dh;
     float s = 0.f;
-    for (int d = 0; d < dh; ++d) s += DT<T>::ld(po + d) * DT<T>::ld(pd + d);
+    if constexpr (VEC) {
+        for (int d = 0; d < dh; d += EPC) {
+            union { uint4 v; T e[EPC]; } a, b;
+            a.v = *reinterpret_cast<const uint4 *>(po + d);
+            b.v = *reinterpret_cast<const uint4 *>(pd + d);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) s += DT<T>::ld(&a.e[e]) * DT<T>::ld(&b.e[e]);
+        }
+    } else {
+        for (int d = 0; d < dh; ++d) s += DT<T>::ld(po + d) * DT<T>::ld(pd + d);
+    }
     delta[(size_t)h * total_q + q] = s;
 }
 
@@ -102,11 +122,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T *o, int ldo, co
 template <typename T, int DHP, bool FAST>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
     constexpr int ES = sizeof(T), EPC = 16 / ES;
-    constexpr int RP = DHP * ES + 16;   // pitch of row-major tiles [row][d]
-    constexpr int TP = TT * ES + 16;    // pitch of transposed tiles [d][row]
+    constexpr int RP = DHP * ES + 16;   // pitch of the natural [row][d] tiles
     constexpr int NS = DHP * ES / 32, NDB = DHP / 32, CPR = DHP / EPC, NCH = TT * CPR / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *ldsK = smem, *ldsV = smem + TT * RP, *ldsKT = smem + 2 * TT * RP;
+    unsigned char *ldsK = smem, *ldsV = smem + TT * RP;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -147,10 +166,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
             const uint4 rv = ld16<T, FAST>(V, a.ldv, kt * TT + row, lk, cc * EPC, dh);
             *reinterpret_cast<uint4 *>(ldsK + row * RP + cc * 16) = rk;
             *reinterpret_cast<uint4 *>(ldsV + row * RP + cc * 16) = rv;
-            union { uint4 v; T e[EPC]; } u;
-            u.v = rk;
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) *reinterpret_cast<T *>(ldsKT + (cc * EPC + e) * TP + row * ES) = u.e[e];
         }
         __syncthreads();
         const int key_lim = a.causal ? min(lk, my_q + 1) : lk;
@@ -168,7 +183,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
                 sacc[e] = p * (dpacc[e] - dlt);                            // dS^T
             }
 #pragma unroll
-            for (int d = 0; d < NDB; ++d) mma_acc<T>(dqacc[d], ldsKT + (d * 32 + lr) * TP + kb * 32 * ES, lh, sacc);  // dQ^T += K^T dS^T
+            for (int d = 0; d < NDB; ++d) mma_acc<T>(dqacc[d], ldsK, RP, kb * 32, d * 32, lane, sacc);  // dQ^T += K^T dS^T
         }
         __syncthreads();
     }
@@ -188,11 +203,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
 template <typename T, int DHP, bool FAST>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
     constexpr int ES = sizeof(T), EPC = 16 / ES;
-    constexpr int RP = DHP * ES + 16, TP = TT * ES + 16;
+    constexpr int RP = DHP * ES + 16;
     constexpr int NS = DHP * ES / 32, NDB = DHP / 32, CPR = DHP / EPC, NCH = TT * CPR / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *ldsQ = smem, *ldsDO = smem + TT * RP, *ldsQT = smem + 2 * TT * RP, *ldsDOT = ldsQT + DHP * TP;
-    float *ldsLse = reinterpret_cast<float *>(ldsDOT + DHP * TP), *ldsDlt = ldsLse + TT;
+    unsigned char *ldsQ = smem, *ldsDO = smem + TT * RP;
+    float *ldsLse = reinterpret_cast<float *>(smem + 2 * TT * RP), *ldsDlt = ldsLse + TT;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -231,14 +246,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
             const uint4 rd = ld16<T, FAST>(DO, a.lddo, qt * TT + row, lq, cc * EPC, dh);
             *reinterpret_cast<uint4 *>(ldsQ + row * RP + cc * 16) = rq;
             *reinterpret_cast<uint4 *>(ldsDO + row * RP + cc * 16) = rd;
-            union { uint4 v; T e[EPC]; } uq, ud;
-            uq.v = rq;
-            ud.v = rd;
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                *reinterpret_cast<T *>(ldsQT + (cc * EPC + e) * TP + row * ES) = uq.e[e];
-                *reinterpret_cast<T *>(ldsDOT + (cc * EPC + e) * TP + row * ES) = ud.e[e];
-            }
         }
         if (tid < TT) {
             const int qq = qt * TT + tid;
@@ -264,8 +271,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
             }
 #pragma unroll
             for (int d = 0; d < NDB; ++d) {
-                mma_acc<T>(dvacc[d], ldsDOT + (d * 32 + lr) * TP + qb * 32 * ES, lh, sacc);   // dV^T += dO^T P
-                mma_acc<T>(dkacc[d], ldsQT + (d * 32 + lr) * TP + qb * 32 * ES, lh, dpacc);   // dK^T += Q^T dS
+                mma_acc<T>(dvacc[d], ldsDO, RP, qb * 32, d * 32, lane, sacc);   // dV^T += dO^T P
+                mma_acc<T>(dkacc[d], ldsQ, RP, qb * 32, d * 32, lane, dpacc);   // dK^T += Q^T dS
             }
         }
         __syncthreads();
@@ -290,8 +297,8 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, hipStream_t st) {
     constexpr int ES = sizeof(T), EPC = 16 / ES;
     const bool fast = (a.dh % EPC == 0) && (a.ldq % EPC == 0) && (a.ldk % EPC == 0) && (a.ldv % EPC == 0) && (a.lddo % EPC == 0) &&
                       aligned16(a.q) && aligned16(a.k) && aligned16(a.v) && aligned16(a.dout);
-    constexpr int RP = DHP * ES + 16, TP = TT * ES + 16;
-    const size_t lds_dq = 2 * TT * RP + DHP * TP, lds_dkv = 2 * TT * RP + 2 * DHP * TP + 2 * TT * sizeof(float);
+    constexpr int RP = DHP * ES + 16;
+    const size_t lds_dq = 2 * TT * RP, lds_dkv = 2 * TT * RP + 2 * TT * sizeof(float);
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_kernel<T, DHP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -300,8 +307,13 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, hipStream_t st) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_kernel<T, DHP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(cdiv(a.total_q * a.H, 256)), dim3(256), 0, st, (const T *)a.o, a.ldo, (const T *)a.dout, a.lddo,
-                       const_cast<float *>(a.delta), a.total_q, a.H, a.dh);
+    const bool vec = (a.dh % EPC == 0) && (a.ldo % EPC == 0) && (a.lddo % EPC == 0) && aligned16(a.o) && aligned16(a.dout);
+    if (vec)
+        hipLaunchKernelGGL((attn_delta_kernel<T, true>), dim3(cdiv(a.total_q * a.H, 256)), dim3(256), 0, st, (const T *)a.o, a.ldo, (const T *)a.dout,
+                           a.lddo, const_cast<float *>(a.delta), a.total_q, a.H, a.dh);
+    else
+        hipLaunchKernelGGL((attn_delta_kernel<T, false>), dim3(cdiv(a.total_q * a.H, 256)), dim3(256), 0, st, (const T *)a.o, a.ldo, (const T *)a.dout,
+                           a.lddo, const_cast<float *>(a.delta), a.total_q, a.H, a.dh);
     ACAI_LAUNCH_CHECK("attn_delta");
     dim3 gq(cdiv(max_q, OB), a.H, B), gk(cdiv(max_k, OB), a.H, B);
     if (fast) {

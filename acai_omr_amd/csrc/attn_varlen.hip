@@ -3,8 +3,8 @@
 // (reference: acai_omr/models/models.py:30-34,186-190,351-360,422-426; masks M:70-73, M:468).
 //
 // gfx950 design.  Workgroup = 4 waves = 128 queries of one (sequence, head); each wave owns 32 queries
-// and streams 64-key K/V tiles that the workgroup stages in LDS (K row-major [key][d], V transposed
-// [d][key]).  Both products are "swapped" so that a query lives on a LANE and keys/d live in REGISTERS:
+// and streams 64-key K/V tiles that the workgroup stages in LDS (both in their natural [key][d] image; the
+// V^T fragments are read with ds_read_b64_tr_b16 - bf16 - or one ds_read_b32 per K=2 MFMA - fp32).  Both products are "swapped" so that a query lives on a LANE and keys/d live in REGISTERS:
 //   S^T[key][q] = K . Q^T   A = K rows (ds_read_b128), B = Q fragments held in registers for the whole kernel
 //   O^T[d][q]   = V^T . P^T A = V^T rows (LDS),          B = P, taken straight from the S^T accumulators
 // With the 32x32 MFMA C/D layout (col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)) the softmax row
@@ -35,13 +35,12 @@ template <typename T, int DHP, bool FAST>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     constexpr int ES = sizeof(T);
     constexpr int EPC = 16 / ES;                 // elements per 16-byte chunk
-    constexpr int KPITCH = DHP * ES + 16;        // bytes per K row in LDS
-    constexpr int VPITCH = KT * ES + 16;         // bytes per V^T row in LDS
+    constexpr int KPITCH = DHP * ES + 16;        // bytes per K / V row in LDS (both tiles keep their natural [key][d] image)
     constexpr int NS = DHP * ES / 32;            // 16-byte fragments per lane along d (per lane-half)
     constexpr int NDB = DHP / 32;                // 32-wide d blocks of the output
     constexpr int CPR = DHP / EPC;               // 16-byte chunks per K/V row
     constexpr int NCH = KT * CPR / 256;          // chunks per thread per operand
-    __shared__ __attribute__((aligned(16))) unsigned char lds[KT * KPITCH + DHP * VPITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * KT * KPITCH];
     unsigned char *ldsK = lds, *ldsV = lds + KT * KPITCH;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -107,11 +106,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + 256 * i, row = c / CPR, cc = c % CPR;
             *reinterpret_cast<uint4 *>(ldsK + row * KPITCH + cc * 16) = rk[i];
-            union { uint4 v; T e[EPC]; } u;
-            u.v = rv[i];
-#pragma unroll
-            for (int e = 0; e < EPC; ++e)  // transpose: V^T[d][key]
-                *reinterpret_cast<T *>(ldsV + (cc * EPC + e) * VPITCH + row * ES) = u.e[e];
+            *reinterpret_cast<uint4 *>(ldsV + row * KPITCH + cc * 16) = rv[i];
         }
     };
 
@@ -187,12 +182,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                     pf.w = pack_bf16(sacc[kb][8 * s2 + 6], sacc[kb][8 * s2 + 7]);
 #pragma unroll
                     for (int d = 0; d < NDB; ++d) {
-                        // A element j = V^T[d][key 16 s2 + 8 (j>>2) + 4 lh + (j&3)]
-                        const unsigned char *vr = ldsV + (d * 32 + lr) * VPITCH + (kb * 32 + 16 * s2 + 4 * lh) * 2;
-                        const uint2 lo = *reinterpret_cast<const uint2 *>(vr);
-                        const uint2 hi = *reinterpret_cast<const uint2 *>(vr + 16);
-                        const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
+                        // A element j = V[key 16 s2 + 8 (j>>2) + 4 lh + (j&3)][d]: two 4-key x 16-d transposing reads of the natural V tile
+                        // (lane 4q+p of a 16-lane group addresses key row q, columns 4p..4p+3; lane i receives column i)
+                        typedef __attribute__((ext_vector_type(4))) short s4;
+                        typedef __attribute__((address_space(3))) s4 *lds_s4;
+                        const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+                        const unsigned char *vr = ldsV + (kb * 32 + 16 * s2 + 4 * lh + (i16 >> 2)) * KPITCH + (d * 32 + 16 * g1 + 4 * (i16 & 3)) * 2;
+                        union { s4 v[2]; uint4 u; } vf;
+                        vf.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(vr));
+                        vf.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(vr + 8 * KPITCH));
+                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf.u),
                                                                          __builtin_bit_cast(bf16x8, pf), oacc[d], 0, 0, 0);
                     }
                 }
@@ -201,11 +200,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 for (int g4 = 0; g4 < 4; ++g4) {
 #pragma unroll
                     for (int d = 0; d < NDB; ++d) {
-                        // A for MFMA step i = 4 g4 + e: V^T[d][key (e) + 8 g4 + 4 lh]
-                        const f32x4 v4 = *reinterpret_cast<const f32x4 *>(ldsV + (d * 32 + lr) * VPITCH + (kb * 32 + 8 * g4 + 4 * lh) * 4);
+                        // A for MFMA step i = 4 g4 + e: V[key e + 8 g4 + 4 lh][d]: one conflict-free ds_read_b32 per K=2 MFMA
+                        const unsigned char *vr = ldsV + (kb * 32 + 8 * g4 + 4 * lh) * KPITCH + (d * 32 + lr) * 4;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(v4[e], sacc[kb][4 * g4 + e], oacc[d], 0, 0, 0);
+                            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(*reinterpret_cast<const float *>(vr + e * KPITCH), sacc[kb][4 * g4 + e], oacc[d], 0, 0, 0);
                     }
                 }
             }

@@ -21,6 +21,7 @@ struct GemmArgs {
     const float *bias, *residual;
     void *C;
     int lda, ldw, ldr, ldc, M, N, K, out_dtype, flags;
+    int ksplit;  // > 0: split-K over `ksplit` workgroups per tile, fp32 atomic accumulation into C (weight gradients: K = rows)
     // EPI == 1 (cross K/V prefill scatter)
     const int32_t *row_seq, *row_pos, *seq_len;
     const int64_t *seq_off;
@@ -88,6 +89,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BM - 1) / BM;
     const int nwg = nbn * nbm;
     int pid = blockIdx.x;
+    int kslice = 0;
+    if (g.ksplit > 1) {
+        kslice = pid / nwg;
+        pid -= kslice * nwg;
+    }
     {
         const int q = nwg / 8, r = nwg % 8, xcd = pid % 8, idx = pid / 8;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -106,7 +112,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     uint4 ra[4], rb[4];
-    const int nkt = (g.K + BK - 1) / BK;
+    int nkt = (g.K + BK - 1) / BK, kt_begin = 0;
+    if (g.ksplit > 1) {
+        const int per = (nkt + g.ksplit - 1) / g.ksplit;
+        kt_begin = kslice * per;
+        nkt = min(nkt, kt_begin + per);
+        if (kt_begin >= nkt) return;  // uniform per workgroup, before any barrier
+    }
 
     // transposed staging: chunk c -> k index c / (128/EPC), row group c % (128/EPC) (consecutive lanes walk the contiguous dim)
     constexpr int RG = 128 / EPC;  // 16-byte row groups per 128-row tile
@@ -157,10 +169,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
         }
     };
 
-    load_tile(0);
+    load_tile(kt_begin);
     store_tile();
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = kt_begin; kt < nkt; ++kt) {
         if (kt + 1 < nkt) load_tile(kt + 1);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -213,6 +225,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
                 const int row = bm0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (row >= g.M) continue;
                 float v = acc[i][j][e] + bv;
+                if constexpr (EPI == 0 && TA && TB) {
+                    if (g.ksplit > 0) {  // weight gradient: accumulate (C is fp32 and was zeroed or holds a running gradient)
+                        atomicAdd(reinterpret_cast<float *>(g.C) + (size_t)row * g.ldc + col, v);
+                        continue;
+                    }
+                }
                 if constexpr (EPI == 0) {
                     if (do_round) v = round_bf16(v);
                     if (do_gelu) {
@@ -243,11 +261,21 @@ int launch(const GemmArgs &g, hipStream_t st) {
     // 16-byte chunks run along K for row-major operands and along the row index for transposed ones
     const bool fast = (g.lda % EPC == 0) && (g.ldw % EPC == 0) && aligned16(g.A) && aligned16(g.W) && (TA ? g.M % EPC == 0 : g.K % EPC == 0) &&
                       (TB ? g.N % EPC == 0 : g.K % EPC == 0);
-    const int nwg = cdiv(g.M, BM) * cdiv(g.N, BN);
+    int nwg = cdiv(g.M, BM) * cdiv(g.N, BN);
+    GemmArgs h = g;
+    if (TA && TB && EPI == 0) {
+        // dW = dY^T X: few output tiles, K = number of rows (1e4..1e5): split K until ~3 workgroups per CU exist
+        constexpr int BKE = ROWB / (int)sizeof(T);
+        const int nkt = cdiv(g.K, BKE);
+        int ks = cdiv(768, nwg);
+        ks = ks < 1 ? 1 : (ks > nkt / 4 ? (nkt / 4 < 1 ? 1 : nkt / 4) : ks);
+        h.ksplit = ks;
+        nwg *= ks;
+    }
     if (fast)
-        hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, true, TA, TB>), dim3(nwg), dim3(256), 0, st, g);
+        hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, true, TA, TB>), dim3(nwg), dim3(256), 0, st, h);
     else
-        hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, false, TA, TB>), dim3(nwg), dim3(256), 0, st, g);
+        hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, false, TA, TB>), dim3(nwg), dim3(256), 0, st, h);
     ACAI_LAUNCH_CHECK("acai_gemm");
     return 0;
 }
@@ -279,6 +307,8 @@ extern "C" int acai_gemm(const void *A, int lda, int trans_a, const void *W, int
     ACAI_CHECK_ARG(M >= 0 && N > 0 && K > 0, "acai_gemm: bad shape M=%d N=%d K=%d", M, N, K);
     ACAI_CHECK_ARG(lda >= (trans_a ? M : K) && ldw >= (trans_w ? N : K) && ldc >= N && (!residual || ldr >= N), "acai_gemm: leading dimension smaller than row");
     ACAI_CHECK_ARG((in_dtype == ACAI_F32 || in_dtype == ACAI_BF16) && (out_dtype == ACAI_F32 || out_dtype == ACAI_BF16), "acai_gemm: bad dtype");
+    ACAI_CHECK_ARG(!(trans_a && trans_w) || (out_dtype == ACAI_F32 && !bias && !residual && !flags),
+                   "acai_gemm: trans_a && trans_w accumulates into an fp32 C (no bias / residual / flags)");
     if (M == 0) return 0;
     GemmArgs g{};
     g.A = A; g.W = W; g.bias = bias; g.residual = residual; g.C = C;

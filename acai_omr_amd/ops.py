@@ -76,7 +76,8 @@ def gemm(a, w, trans_a=False, trans_w=False, bias=None, residual=None, out_dtype
     N, K2 = (w.shape[1], w.shape[0]) if trans_w else w.shape
     assert K == K2, (a.shape, w.shape, trans_a, trans_w)
     if out is None:
-        out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+        # the weight-gradient form accumulates (split-K atomics) into an fp32 output
+        out = torch.zeros(M, N, dtype=torch.float32, device=a.device) if (trans_a and trans_w) else torch.empty(M, N, dtype=out_dtype, device=a.device)
     assert out.shape == (M, N) and out.stride(1) == 1
     if residual is not None:
         assert residual.dtype == torch.float32 and residual.shape == (M, N) and residual.stride(1) == 1

@@ -48,7 +48,9 @@ int acai_gemm_nt(const void *A, int lda, const void *W, int ldw, const float *bi
 /* The same contraction with either operand stored reduction-major, for the backward of nn.Linear (autograd of M:29,57,...):
  *   dX = dY . W   -> acai_gemm(dY, ldy, 0,  W, ldw, 1, ...)  (M = rows, N = in_features, K = out_features)
  *   dW = dY^T . X -> acai_gemm(dY, ldy, 1,  X, ldx, 1, ...)  (M = out_features, N = in_features, K = rows)
- * trans_a: A stored [K][M]; trans_w: W stored [K][N].  residual may alias C (gradient accumulation). */
+ * trans_a: A stored [K][M]; trans_w: W stored [K][N].  residual may alias C.
+ * trans_a && trans_w (weight gradient, K = number of rows): C must be fp32 and is ACCUMULATED into with fp32 atomics
+ * (split-K over workgroups); zero it for a fresh gradient.  No bias / residual / flags in that form. */
 int acai_gemm(const void *A, int lda, int trans_a, const void *W, int ldw, int trans_w, const float *bias, const float *residual, int ldr,
               void *C, int ldc, int M, int N, int K, int in_dtype, int out_dtype, int flags, void *stream);
 
