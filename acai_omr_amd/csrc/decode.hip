@@ -213,16 +213,14 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
         // 2. activation image: wave w takes rows w, w+4 (together), then w+8, w+12; lane takes 4-element groups
         if (a.ablate & 2) {
         } else if constexpr (XBF16) {
-            // plain copy of the bf16 rows; every load of a row is issued before its first LDS store
+            // plain copy of the bf16 rows (global loads and LDS stores do not alias: the compiler hoists the loads of a row)
             for (int b0 = wave; b0 < nb; b0 += NW) {
                 const bf16_t *xr0 = reinterpret_cast<const bf16_t *>(a.x) + (size_t)(bt + b0) * a.ldx;
-                uint4 t0[SKM_MAXK / 512];
 #pragma unroll
-                for (int j = 0; j < SKM_MAXK / 512; ++j)
-                    if (j * 512 + lane * 8 < K) t0[j] = *reinterpret_cast<const uint4 *>(xr0 + j * 512 + lane * 8);
-#pragma unroll
-                for (int j = 0; j < SKM_MAXK / 512; ++j)
-                    if (j * 512 + lane * 8 < K) *reinterpret_cast<uint4 *>(xs + b0 * pitch + (j * 512 + lane * 8) * 2) = t0[j];
+                for (int j = 0; j < SKM_MAXK / 512; ++j) {
+                    const int k = j * 512 + lane * 8;
+                    if (k < K) *reinterpret_cast<uint4 *>(xs + b0 * pitch + k * 2) = *reinterpret_cast<const uint4 *>(xr0 + k);
+                }
             }
         } else if constexpr (NV <= 4) {
             for (int b0 = wave; b0 < nb; b0 += 2 * NW) {
@@ -379,7 +377,7 @@ int launch_skinny(const SkinnyArgs &a, hipStream_t st) {
             static const int abl = getenv("ACAI_SKINNY_ABLATE") ? atoi(getenv("ACAI_SKINNY_ABLATE")) : 0;
             static const int rpb = getenv("ACAI_SKINNY_ROWS") ? atoi(getenv("ACAI_SKINNY_ROWS")) : 0;
             b.ablate = abl;
-            b.rows_per_block = rpb ? rpb : (a.N >= 3200 ? 16 : (a.N >= 1600 ? 8 : 4));
+            b.rows_per_block = rpb ? rpb : (a.N >= 2560 ? 16 : (a.N >= 1600 ? 8 : 4));
             const dim3 grid(cdiv(a.N, b.rows_per_block));
             if (wide)
                 hipLaunchKernelGGL((skinny_mfma_kernel<true, 1, 16>), grid, dim3(1024), lds, st, b);

@@ -236,8 +236,14 @@ def main():
         step_bytes = w_bytes + a.batch * 12 * 2 * (S + t_mid) * 1024 * 2
         k_s = time_cross_attn_kernel(eng)
         k_bytes = sum(lens) * 2 * eng.E * 2   # K and V rows of every sequence, bf16, one layer
+        # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950
+        # correction applied - profiles/r01_pmc_cross_attn.json); only quoted when it was measured on this workload shape
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_cross_attn.json")
+        if os.path.exists(pmc) and a.batch == 8 and S == 4096:
+            traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
         roof = dict(bound="hbm", kernel="decode_attn_kernel<bf16,8,RAGGED> (cross-attention K/V stream, one layer, all sequences)",
-                    achieved=k_bytes / k_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=k_bytes / k_s / 1e9 / HBM_PEAK_GBS, traffic=None,
+                    achieved=k_bytes / k_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=k_bytes / k_s / 1e9 / HBM_PEAK_GBS, traffic=traffic,
                     kernel_us=k_s * 1e6, bytes_per_launch=k_bytes,
                     step_bytes=step_bytes, step_achieved_GBs=step_bytes / (dt / a.steps) / 1e9)
         out = dict(metric="LMX tokens/sec (greedy decode, KV cache)", value=tokens / dt, unit="tokens/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
