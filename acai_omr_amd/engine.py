@@ -303,6 +303,30 @@ class DecodeEngine:
         cur.wait_stream(self.stream)
         return out
 
+    def greedy_chunks(self, max_len, chunk):
+        """Generator over the greedy loop in chunks of `chunk` tokens (streamed inference): yields (tokens_done, all_finished)
+        after each chunk; the decode graph is replayed on the engine's stream, the caller's stream waits for it."""
+        if max_len > self.Tmax:
+            raise RuntimeError(f"{max_len} decoding steps is too long for max sequence length of {self.Tmax}")
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.arm(self.B)
+            g = self.ensure_graph()
+        done, total = 0, max_len - 1
+        while done < total:
+            n = min(chunk, total - done)
+            with torch.cuda.stream(self.stream):
+                for _ in range(n):
+                    g.launch()
+                fin = int(self.finished[self.B].item()) == 0
+            cur.wait_stream(self.stream)
+            done += n
+            self.cache_len = done
+            yield done, fin
+            if fin:
+                return
+
     def arm(self, B):
         own = self.omr
         self.seqs[:B].fill_(own.pad_idx)

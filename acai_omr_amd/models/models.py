@@ -496,52 +496,14 @@ class ViTOMR(nn.Module):
             raise RuntimeError("Trying to use cached inference pathway with an uncached TransformerDecoder instance")
         blocks.prepare_caches_packed(mem32, None, lens)
         eng = blocks.engine(self.decoder.pos_embedding.device)
-        # replay the graph flush_interval tokens at a time; after each chunk hand out the freshly written tokens
-        t_done = 0
-        total = max_len - 1
-        gen = _ChunkedGreedy(eng, max_len, flush_interval)
-        for t_done, finished in gen:
-            if finished or t_done >= total:
+        # replay the decode graph flush_interval tokens at a time; after each chunk hand out the freshly written tokens
+        for t_done, finished in eng.greedy_chunks(max_len, flush_interval):
+            if finished or t_done >= max_len - 1:
                 break
             buf = eng.seqs[:1, t_done - flush_interval + 1:t_done + 1].to(torch.int)
             yield {"type": InferenceEvent.STEP.value, "payload": {"tokens": buf}}
         seqs, lps, mask = self.mask_and_clip_seqs(eng.seqs[:1, :max_len].clone(), eng.logprobs[:1, :max_len].clone())
         yield {"type": InferenceEvent.INFERENCE_FINISH.value, "payload": {"sequence": seqs, "log_probs": lps, "mask": mask}}
-
-
-class _ChunkedGreedy:
-    """Iterator over DecodeEngine.greedy in chunks of `chunk` tokens: yields (tokens_done, all_finished)."""
-
-    def __init__(self, eng, max_len, chunk):
-        self.eng, self.max_len, self.chunk = eng, max_len, chunk
-
-    def __iter__(self):
-        marks = []
-        # greedy() polls every `chunk` steps and calls on_chunk after each; run it chunk by chunk through a generator
-        eng = self.eng
-        B = eng.B
-        import ctypes
-
-        from .. import _lib
-        own = eng.omr
-        eng.seqs[:B].fill_(own.pad_idx)
-        eng.seqs[:B, 0] = own.bos_idx
-        eng.logprobs[:B].zero_()
-        eng.finished.zero_()
-        eng.reset_self_cache()
-        eng.step.copy_(torch.tensor([1, 0], dtype=torch.int32))
-        done, total = 0, self.max_len - 1
-        while done < total:
-            n = min(self.chunk, total - done)
-            for _ in range(n):
-                _lib.check(_lib.lib().acai_decode_step(ctypes.byref(eng._desc), ops._st()), "acai_decode_step")
-            done += n
-            eng.cache_len = done
-            fin = int(eng.finished[B].item()) == 0
-            marks.append(done)
-            yield done, fin
-            if fin:
-                return
 
 
 class TeacherForcedViTOMR(ViTOMR):

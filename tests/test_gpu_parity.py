@@ -309,3 +309,29 @@ def test_full_size_decoder_ragged_batch_vs_oracle(dev, prec):
                 first = int(bad[0])
                 assert float(margin[b, first]) <= 0.13, (b, first, float(margin[b, first]))
         assert same.float().mean() > 0.8
+
+
+def test_streamed_inference_events_match_batch_inference(dev):
+    """streamed_inference (vitomr_inference.py:51-70 / models.py:625-647): event order, STEP payloads every flush_interval tokens,
+    final sequence identical to inference(); single image only."""
+    from acai_omr_amd.config import InferenceEvent
+    from acai_omr_amd.inference.vitomr_inference import inference, streamed_inference
+    fx = load_golden("vitomr_dh64")
+    cfg = fx["cfg"]
+    m = build_vitomr(cfg, fx["state_dict"], dev, torch.bfloat16)
+    img = fx["imgs"][1]
+    seqs, lps, mask = inference(m, img, dev, max_inference_len=cfg["gen_len"])
+    events = list(streamed_inference(img, m, dev, max_inference_len=cfg["gen_len"], flush_interval=3))
+    kinds = [e["type"] for e in events]
+    assert kinds[0] == InferenceEvent.ENCODING_START.value and kinds[1] == InferenceEvent.ENCODING_FINISH.value
+    assert kinds[-1] == InferenceEvent.INFERENCE_FINISH.value and set(kinds[2:-1]) <= {InferenceEvent.STEP.value}
+    fin = events[-1]["payload"]
+    assert torch.equal(fin["sequence"], seqs) and torch.equal(fin["mask"], mask)
+    steps = [e["payload"]["tokens"] for e in events if e["type"] == InferenceEvent.STEP.value]
+    assert len(steps) >= 2 and all(t.shape == (1, 3) and t.dtype == torch.int for t in steps)
+    streamed = torch.cat(steps, dim=1).long()
+    assert torch.equal(streamed[0], seqs[0, 1:1 + streamed.shape[1]])
+    with pytest.raises(ValueError):
+        with torch.no_grad():
+            lat, msk = m.encoder(fx["imgs"])
+            list(m.streamed_cached_greedy_generate(m.transition_head(lat), msk))
