@@ -145,6 +145,13 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
 // LN on load, published (mean, rstd) for the residual path of a later launch, bf16 activations in / out.
 constexpr int SKM_MAXK = 4096;
 
+// 16-byte non-temporal load: decoder weights (and K/V) are read exactly once per decode step
+__device__ __forceinline__ uint4 ld_nt16(const void *p) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 template <int NV>
 __device__ __forceinline__ void skm_row_stats(const float4 (&v)[NV], int K, int lane, float eps, float &mean, float &rstd) {
     float s = 0.f;
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             wf[c] = make_uint4(0, 0, 0, 0);
-            if (c < nch && row_ok) wf[c] = *reinterpret_cast<const uint4 *>(Wrow + 32 * c);
+            if (c < nch && row_ok) wf[c] = ld_nt16(Wrow + 32 * c);
         }
         // 1b. wave 0 also fetches everything its epilogue needs now, so that nothing is loaded after the reduction
         float e_bias[4] = {0.f, 0.f, 0.f, 0.f}, e_res[4] = {0.f, 0.f, 0.f, 0.f}, e_rw[4] = {1.f, 1.f, 1.f, 1.f}, e_rb[4] = {0.f, 0.f, 0.f, 0.f};
@@ -238,9 +245,27 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
                         }
                     }
                 if (a.ln_w) {
-                    float m0, s0, m1, s1;
-                    skm_row_stats<NV>(v0, K, lane, a.ln_eps, m0, s0);
-                    skm_row_stats<NV>(v1, K, lane, a.ln_eps, m1, s1);
+                    // both rows' sum and sum of squares ride the same 6 cross-lane steps (4 independent chains); one-pass variance
+                    // E[x^2] - mean^2 is accurate to ~1e-6 relative for O(1) activations and this path rounds to bf16 right after
+                    float t0 = 0.f, u0 = 0.f, t1 = 0.f, u1 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NV; ++j)
+                        if (j * 256 + lane * 4 < K) {
+                            t0 += (v0[j].x + v0[j].y) + (v0[j].z + v0[j].w);
+                            u0 += (v0[j].x * v0[j].x + v0[j].y * v0[j].y) + (v0[j].z * v0[j].z + v0[j].w * v0[j].w);
+                            t1 += (v1[j].x + v1[j].y) + (v1[j].z + v1[j].w);
+                            u1 += (v1[j].x * v1[j].x + v1[j].y * v1[j].y) + (v1[j].z * v1[j].z + v1[j].w * v1[j].w);
+                        }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        t0 += __shfl_xor(t0, o);
+                        u0 += __shfl_xor(u0, o);
+                        t1 += __shfl_xor(t1, o);
+                        u1 += __shfl_xor(u1, o);
+                    }
+                    const float invK = 1.0f / (float)K;
+                    const float m0 = t0 * invK, m1 = t1 * invK;
+                    const float s0 = 1.0f / sqrtf(fmaxf(u0 * invK - m0 * m0, 0.f) + a.ln_eps), s1 = 1.0f / sqrtf(fmaxf(u1 * invK - m1 * m1, 0.f) + a.ln_eps);
                     if (lane == 0 && a.stats_out && blockIdx.x == 0) {
                         a.stats_out[(bt + b0) * 2] = m0;
                         a.stats_out[(bt + b0) * 2 + 1] = s0;
@@ -304,7 +329,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
             for (int c = 0; c < 8; ++c) {  // next batch of weight fragments (none when NW covers K in one batch)
                 wn[c] = make_uint4(0, 0, 0, 0);
                 if constexpr (NW * 256 < SKM_MAXK)
-                    if (c0 + 8 + c < nch && row_ok) wn[c] = *reinterpret_cast<const uint4 *>(Wrow + 32 * (c0 + 8 + c));
+                    if (c0 + 8 + c < nch && row_ok) wn[c] = ld_nt16(Wrow + 32 * (c0 + 8 + c));
             }
 #pragma unroll
             for (int c = 0; c < 8; ++c)
@@ -469,8 +494,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DAttnArgs a) {
             const int key = key0 + u * 4 * KPW;
             kk[u] = vv[u] = make_uint4(0, 0, 0, 0);
             if (key < c1) {
-                kk[u] = *reinterpret_cast<const uint4 *>(Kp + (size_t)key * a.dhp + kq * EPC);
-                vv[u] = *reinterpret_cast<const uint4 *>(Vp + (size_t)key * a.dhp + kq * EPC);
+                // every K/V byte is read exactly once per step: non-temporal loads (streaming cache policy)
+                kk[u] = ld_nt16(Kp + (size_t)key * a.dhp + kq * EPC);
+                vv[u] = ld_nt16(Vp + (size_t)key * a.dhp + kq * EPC);
             }
         }
 #pragma unroll
