@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
         }
         __syncthreads();
         const int key_lim = a.causal ? min(lk, my_q + 1) : lk;
+        const bool interior = (kt + 1) * TT <= (a.causal ? min(lk, q0 + wave * 32 + 1) : lk);  // every key valid for the whole wave
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16 sacc, dpacc;
@@ -176,11 +177,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
             for (int e = 0; e < 16; ++e) sacc[e] = dpacc[e] = 0.f;
             mma_rows<T, NS>(sacc, ldsK + kb * 32 * RP, RP, lr, lh, qf);     // S^T[key][q]
             mma_rows<T, NS>(dpacc, ldsV + kb * 32 * RP, RP, lr, lh, dof);   // dP^T[key][q]
+            if (interior) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = kt * TT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const float p = key < key_lim ? exp2f(sacc[e] * a.scale_log2e - lse) : 0.f;
-                sacc[e] = p * (dpacc[e] - dlt);                            // dS^T
+                for (int e = 0; e < 16; ++e) sacc[e] = fast_exp2(fmaf(sacc[e], a.scale_log2e, -lse)) * (dpacc[e] - dlt);   // dS^T
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kt * TT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const float p = key < key_lim ? fast_exp2(sacc[e] * a.scale_log2e - lse) : 0.f;
+                    sacc[e] = p * (dpacc[e] - dlt);                        // dS^T
+                }
             }
 #pragma unroll
             for (int d = 0; d < NDB; ++d) mma_acc<T>(dqacc[d], ldsK, RP, kb * 32, d * 32, lane, sacc);  // dQ^T += K^T dS^T
@@ -261,13 +267,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
             for (int e = 0; e < 16; ++e) sacc[e] = dpacc[e] = 0.f;
             mma_rows<T, NS>(sacc, ldsQ + qb * 32 * RP, RP, lr, lh, kf);      // S[q][key]
             mma_rows<T, NS>(dpacc, ldsDO + qb * 32 * RP, RP, lr, lh, vf);    // dP[q][key]
+            // row statistics of the 16 query rows this lane holds: rows 8 g4 + 4 lh + (0..3) are contiguous -> one 16-byte LDS read each
+            f32x4 lse4[4], dlt4[4];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int ql = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, qq = qt * TT + ql;
-                const bool ok = qq < lq && my_k < lk && (!a.causal || my_k <= qq);
-                const float p = ok ? exp2f(sacc[e] * a.scale_log2e - ldsLse[ql]) : 0.f;
-                sacc[e] = p;                                  // P
-                dpacc[e] = p * (dpacc[e] - ldsDlt[ql]);       // dS
+            for (int g4 = 0; g4 < 4; ++g4) {
+                lse4[g4] = *reinterpret_cast<const f32x4 *>(ldsLse + qb * 32 + 8 * g4 + 4 * lh);
+                dlt4[g4] = *reinterpret_cast<const f32x4 *>(ldsDlt + qb * 32 + 8 * g4 + 4 * lh);
+            }
+            // interior: every query of the tile exists, every key of the WAVE exists and (causal) lies at or before the tile's first query
+            const bool interior = (qt + 1) * TT <= lq && k0 + wave * 32 + 32 <= lk && (!a.causal || k0 + wave * 32 + 31 <= qt * TT + qb * 32);
+            if (interior) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float p = fast_exp2(fmaf(sacc[e], a.scale_log2e, -lse4[e >> 2][e & 3]));
+                    sacc[e] = p;                                           // P
+                    dpacc[e] = p * (dpacc[e] - dlt4[e >> 2][e & 3]);       // dS
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ql = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, qq = qt * TT + ql;
+                    const bool ok = qq < lq && my_k < lk && (!a.causal || my_k <= qq);
+                    const float p = ok ? fast_exp2(sacc[e] * a.scale_log2e - lse4[e >> 2][e & 3]) : 0.f;
+                    sacc[e] = p;
+                    dpacc[e] = p * (dpacc[e] - dlt4[e >> 2][e & 3]);
+                }
             }
 #pragma unroll
             for (int d = 0; d < NDB; ++d) {

@@ -137,32 +137,55 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         }
 
         // ---- mask + online softmax (per-lane query) ----------------------------------------------------
+        // At d_h <= 64 this VALU block, not the MFMAs, bounds the kernel: interior tiles (every key valid for every query of the
+        // wave) take a path without compares / selects: 1 max + 1 fma + 1 exp2 + 1 add per score.
         const int key_lim = a.causal ? min(lk, my_q + 1) : lk;  // keys < key_lim are attended
-        float tmax = -1.0e30f;
+        const int wave_lim = a.causal ? min(lk, q0 + wave * 32 + 1) : lk;  // keys < wave_lim are valid for ALL lanes of the wave
+        float psum = 0.f, alpha;
+        if ((kt + 1) * KT <= wave_lim) {
+            float tmax = -1.0e30f;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = kt * KT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const float sv = key < key_lim ? sacc[kb][e] * a.scale_log2e : -1.0e30f;
-                sacc[kb][e] = sv;
-                tmax = fmaxf(tmax, sv);
-            }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
+                for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[kb][e]);
+            tmax *= a.scale_log2e;
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float m_new = fmaxf(m_run, tmax);
+            alpha = fast_exp2(m_run - m_new);
+            m_run = m_new;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                // masked entries: exp2(-1e30 - m) = 0 once m is finite; a fully masked row keeps m = -1e30 and
-                // p = exp2(0) = 1 would be wrong, so gate on the mask value itself
-                const float p = sacc[kb][e] > -0.5e30f ? exp2f(sacc[kb][e] - m_new) : 0.f;
-                sacc[kb][e] = p;
-                psum += p;
-            }
+                for (int e = 0; e < 16; ++e) {
+                    const float p = fast_exp2(fmaf(sacc[kb][e], a.scale_log2e, -m_new));
+                    sacc[kb][e] = p;
+                    psum += p;
+                }
+        } else {
+            float tmax = -1.0e30f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kt * KT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const float sv = key < key_lim ? sacc[kb][e] * a.scale_log2e : -1.0e30f;
+                    sacc[kb][e] = sv;
+                    tmax = fmaxf(tmax, sv);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float m_new = fmaxf(m_run, tmax);
+            alpha = fast_exp2(m_run - m_new);
+            m_run = m_new;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    // masked entries: gate on the mask value itself (a fully masked row keeps m = -1e30 and exp2(0) = 1 would be wrong)
+                    const float p = sacc[kb][e] > -0.5e30f ? fast_exp2(sacc[kb][e] - m_new) : 0.f;
+                    sacc[kb][e] = p;
+                    psum += p;
+                }
+        }
         l_run = l_run * alpha + psum;
 #pragma unroll
         for (int d = 0; d < NDB; ++d)

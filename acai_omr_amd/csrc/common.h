@@ -36,6 +36,10 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 __device__ __forceinline__ float round_bf16(float f) { return bf2f(f2bf(f)); }
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
+// 2^x as the bare v_exp_f32 (exp2f() adds a denormal-range fix-up of ~4 VALU ops per call; softmax arguments are <= 0 and
+// results below 2^-126 may flush to zero)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // exact-erf GELU, as torch's F.gelu(approximate="none")
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DAttnArgs a) {
             for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o);
             if (key < c1) {  // uniform inside a lane group
                 s *= a.scale_log2e;
-                const float mn = fmaxf(m, s), al = exp2f(m - mn), p = exp2f(s - mn);
+                const float mn = fmaxf(m, s), al = fast_exp2(m - mn), p = fast_exp2(s - mn);
                 m = mn;
                 l = l * al + p;
 #pragma unroll
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DAttnArgs a) {
     float mw = m;
 #pragma unroll
     for (int o = LPK; o < 64; o <<= 1) mw = fmaxf(mw, __shfl_xor(mw, o));
-    const float f = exp2f(m - mw);
+    const float f = fast_exp2(m - mw);
     l *= f;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) acc[e] *= f;
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DAttnArgs a) {
         float v = 0.f, lsum = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const float f = exp2f(red[w][0] - M);
+            const float f = fast_exp2(red[w][0] - M);
             v += red[w][tid] * f;
             lsum += red[w][1] * f;
         }
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DAttnArgs a) {
             for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, ld(s * (a.dhp + 2)));
             float l = 0.f, o = 0.f;
             for (int s = 0; s < a.nsplit; ++s) {
-                const float w = exp2f(ld(s * (a.dhp + 2)) - M);
+                const float w = fast_exp2(ld(s * (a.dhp + 2)) - M);
                 l += ld(s * (a.dhp + 2) + 1) * w;
                 o += ld(s * (a.dhp + 2) + 2 + tid) * w;
             }
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(const float *partial, 
     for (int s = 0; s < nsplit; ++s) M = fmaxf(M, p[s * (dhp + 2)]);
     float l = 0.f, o = 0.f;
     for (int s = 0; s < nsplit; ++s) {
-        const float w = exp2f(p[s * (dhp + 2)] - M);
+        const float w = fast_exp2(p[s * (dhp + 2)] - M);
         l += p[s * (dhp + 2) + 1] * w;
         if (d < dhp) o += p[s * (dhp + 2) + 2 + d] * w;
     }
