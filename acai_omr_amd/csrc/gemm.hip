@@ -10,6 +10,8 @@
 // ds_read_b128 feeds four K=2 MFMAs because lane-half h takes k = 8s+4h+j, j = 0..3).
 // Global -> register prefetch of tile t+1 is issued before the MFMAs of tile t (issue-early /
 // write-late staging), one LDS stage, ~3 workgroups per CU cover each other's barriers.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -45,6 +47,60 @@ __device__ __forceinline__ uint4 load_chunk(const T *base, int ld, int row, int 
         r = u.v;
     }
     return r;
+}
+
+// ---- epilogue shared by both main loops: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----------------
+template <int EPI, bool ACCUM>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&acc)[2][2], int bm0, int bn0, int wm, int wn, int lr, int lh) {
+    constexpr bool TA = ACCUM, TB = ACCUM;
+    const bool do_gelu = g.flags & ACAI_GEMM_GELU, do_round = g.flags & ACAI_GEMM_ROUND_BF16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = bn0 + wn * 64 + j * 32 + lr;
+        if (col >= g.N) continue;
+        const float bv = g.bias ? g.bias[col] : 0.f;
+        int kv = 0, hh = 0, dd = 0;
+        if constexpr (EPI == 1) {
+            kv = col / g.E;
+            const int e = col - kv * g.E;
+            hh = e / g.dh;
+            dd = e - hh * g.dh;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = bm0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (row >= g.M) continue;
+                float v = acc[i][j][e] + bv;
+                if constexpr (EPI == 0 && TA && TB) {
+                    if (g.ksplit > 0) {  // weight gradient: accumulate (C is fp32 and was zeroed or holds a running gradient)
+                        atomicAdd(reinterpret_cast<float *>(g.C) + (size_t)row * g.ldc + col, v);
+                        continue;
+                    }
+                }
+                if constexpr (EPI == 0) {
+                    if (do_round) v = round_bf16(v);
+                    if (do_gelu) {
+                        v = gelu_erf(v);
+                        if (do_round) v = round_bf16(v);
+                    }
+                    if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
+                    if (g.out_dtype == ACAI_BF16)
+                        reinterpret_cast<bf16_t *>(g.C)[(size_t)row * g.ldc + col] = f2bf(v);
+                    else
+                        reinterpret_cast<float *>(g.C)[(size_t)row * g.ldc + col] = v;
+                } else {
+                    const int b = g.row_seq[row], s = g.row_pos[row];
+                    const int64_t off = g.seq_off[b] + ((int64_t)hh * g.seq_len[b] + s) * g.dhp + dd;
+                    void *dst = kv ? g.v_out : g.k_out;
+                    if (g.out_dtype == ACAI_BF16)
+                        reinterpret_cast<bf16_t *>(dst)[off] = f2bf(v);
+                    else
+                        reinterpret_cast<float *>(dst)[off] = v;
+                }
+            }
+    }
 }
 
 // Transposed storage (backward GEMMs: dX = dY.W reads W as [K][N]; dW = dY^T.X reads both operands reduction-major):
@@ -204,55 +260,88 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
         }
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) -----------------------
-    const bool do_gelu = g.flags & ACAI_GEMM_GELU, do_round = g.flags & ACAI_GEMM_ROUND_BF16;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = bn0 + wn * 64 + j * 32 + lr;
-        if (col >= g.N) continue;
-        const float bv = g.bias ? g.bias[col] : 0.f;
-        int kv = 0, hh = 0, dd = 0;
-        if constexpr (EPI == 1) {
-            kv = col / g.E;
-            const int e = col - kv * g.E;
-            hh = e / g.dh;
-            dd = e - hh * g.dh;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = bm0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (row >= g.M) continue;
-                float v = acc[i][j][e] + bv;
-                if constexpr (EPI == 0 && TA && TB) {
-                    if (g.ksplit > 0) {  // weight gradient: accumulate (C is fp32 and was zeroed or holds a running gradient)
-                        atomicAdd(reinterpret_cast<float *>(g.C) + (size_t)row * g.ldc + col, v);
-                        continue;
-                    }
-                }
-                if constexpr (EPI == 0) {
-                    if (do_round) v = round_bf16(v);
-                    if (do_gelu) {
-                        v = gelu_erf(v);
-                        if (do_round) v = round_bf16(v);
-                    }
-                    if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
-                    if (g.out_dtype == ACAI_BF16)
-                        reinterpret_cast<bf16_t *>(g.C)[(size_t)row * g.ldc + col] = f2bf(v);
-                    else
-                        reinterpret_cast<float *>(g.C)[(size_t)row * g.ldc + col] = v;
-                } else {
-                    const int b = g.row_seq[row], s = g.row_pos[row];
-                    const int64_t off = g.seq_off[b] + ((int64_t)hh * g.seq_len[b] + s) * g.dhp + dd;
-                    void *dst = kv ? g.v_out : g.k_out;
-                    if (g.out_dtype == ACAI_BF16)
-                        reinterpret_cast<bf16_t *>(dst)[off] = f2bf(v);
-                    else
-                        reinterpret_cast<float *>(dst)[off] = v;
-                }
-            }
+    gemm_epilogue<EPI, TA && TB>(g, acc, bm0, bn0, wm, wn, lr, lh);
+}
+
+// ---- NT main loop with direct-to-LDS staging (global_load_lds, 16 B per lane) ------------------------------------------------
+// For row-major operands with K % BK == 0: no staging VGPRs, two LDS stages (64 KB), tile t+1 in flight while tile t feeds the MFMAs,
+// one barrier per K-step.  An LDS-DMA wave instruction writes 1 KiB linearly (lane l -> base + 16 l = row l/8, slot l%8 of an unpadded
+// 128-byte row), so the bank-conflict fix is an XOR swizzle applied on BOTH sides: lane l fetches the global chunk (l%8) ^ (row%8) and
+// the fragment read of logical chunk c goes to slot c ^ (row%8).  Rows beyond M / N are clamped (their outputs are never stored).
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs g) {
+    constexpr int BK = ROWB / sizeof(T);
+    constexpr int STAGE = (BM + BN) * ROWB;  // 32 KB
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+    const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BM - 1) / BM, nwg = nbn * nbm;
+    int pid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = pid % 8, idx = pid / 8;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    const int bm0 = (pid / nbn) * BM, bn0 = (pid % nbn) * BN;
+    const T *A = reinterpret_cast<const T *>(g.A);
+    const T *W = reinterpret_cast<const T *>(g.W);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // this lane's source chunk inside an 8-row group: row l/8, swizzled slot
+    const int grow = lane >> 3, gslot = (lane & 7) ^ (grow & 7);
+    const T *srcA[4], *srcW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + grow;
+        srcA[i] = A + (size_t)min(bm0 + row, g.M - 1) * g.lda + gslot * (16 / sizeof(T));
+        srcW[i] = W + (size_t)min(bn0 + row, g.N - 1) * g.ldw + gslot * (16 / sizeof(T));
+    }
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    typedef const __attribute__((address_space(1))) void *glb_ptr;
+    auto issue = [&](int kt, int stage) {
+        unsigned char *base = lds + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_ptr)(srcA[i] + (size_t)kt * BK), (lds_ptr)(base + (wave * 4 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(srcW[i] + (size_t)kt * BK), (lds_ptr)(base + BM * ROWB + (wave * 4 + i) * 1024), 16, 0, 0);
+        }
+    };
+    const int nkt = g.K / BK;
+    issue(0, 0);
+    __syncthreads();  // with an LDS-DMA in flight this is s_waitcnt vmcnt(0) + s_barrier
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
+        const unsigned char *sa = lds + (kt & 1) * STAGE, *sb = sa + BM * ROWB;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            uint4 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ra = wm * 64 + i * 32 + lr, rb = wn * 64 + i * 32 + lr;
+                fa[i] = *reinterpret_cast<const uint4 *>(sa + ra * ROWB + (((s * 2 + lh) ^ (ra & 7)) << 4));
+                fb[i] = *reinterpret_cast<const uint4 *>(sb + rb * ROWB + (((s * 2 + lh) ^ (rb & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (sizeof(T) == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+                    } else {
+                        const f32x4 a4 = __builtin_bit_cast(f32x4, fa[i]), b4 = __builtin_bit_cast(f32x4, fb[j]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+        __syncthreads();  // tile kt+1 has landed (vmcnt(0)) and every wave is done reading stage kt&1
+    }
+    gemm_epilogue<EPI, false>(g, acc, bm0, bn0, wm, wn, lr, lh);
 }
 
 template <typename T, int EPI, bool TA = false, bool TB = false>
@@ -272,7 +361,11 @@ int launch(const GemmArgs &g, hipStream_t st) {
         h.ksplit = ks;
         nwg *= ks;
     }
-    if (fast)
+    constexpr int BKG = ROWB / (int)sizeof(T);
+    static const bool no_glds = getenv("ACAI_GEMM_NO_GLDS") != nullptr;
+    if (fast && !TA && !TB && g.K % BKG == 0 && !no_glds)
+        hipLaunchKernelGGL((gemm_nt_glds_kernel<T, EPI>), dim3(nwg), dim3(256), 0, st, h);
+    else if (fast)
         hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, true, TA, TB>), dim3(nwg), dim3(256), 0, st, h);
     else
         hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, false, TA, TB>), dim3(nwg), dim3(256), 0, st, h);
