@@ -23,6 +23,7 @@ struct GemmArgs {
     const float *bias, *residual;
     void *C;
     int lda, ldw, ldr, ldc, M, N, K, out_dtype, flags;
+    int vec_epi; // host-checked: C (and the residual) allow 16-byte row accesses -> LDS-transposed epilogue
     int ksplit;  // > 0: split-K over `ksplit` workgroups per tile, fp32 atomic accumulation into C (weight gradients: K = rows)
     // EPI == 1 (cross K/V prefill scatter)
     const int32_t *row_seq, *row_pos, *seq_len;
@@ -341,7 +342,69 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs g) {
         }
         __syncthreads();  // tile kt+1 has landed (vmcnt(0)) and every wave is done reading stage kt&1
     }
-    gemm_epilogue<EPI, false>(g, acc, bm0, bn0, wm, wn, lr, lh);
+    // ---- epilogue ---------------------------------------------------------------------------------------------------------
+    // The MFMA C/D layout gives a lane one column and 16 scattered rows: storing from it means 2- or 4-byte stores in 64/128-byte
+    // runs, which bounds the short-K GEMMs (K = 512..768: 8-12 K-steps per 128x128 output tile).  Each wave therefore transposes its
+    // 64x64 block through its own 16 KB of the (now free) LDS, 32 rows at a time, and writes 16 bytes per lane along the rows; bias /
+    // bf16 rounding / GELU are applied on the way in, the fp32 residual on the way out.
+    constexpr int EP = 68;  // floats per staged row (64 + 4: 16-byte aligned rows, conflict-light)
+    const int ldc_e = g.ldc, n_valid = g.N - (bn0 + wn * 64);
+    if (EPI != 0 || !g.vec_epi) {
+        gemm_epilogue<EPI, false>(g, acc, bm0, bn0, wm, wn, lr, lh);
+        return;
+    }
+    float *stg = reinterpret_cast<float *>(lds + wave * 16384);
+    const bool do_gelu = g.flags & ACAI_GEMM_GELU, do_round = g.flags & ACAI_GEMM_ROUND_BF16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = bn0 + wn * 64 + j * 32 + lr;
+            const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[i][j][e] + bv;
+                if (do_round) v = round_bf16(v);
+                if (do_gelu) {
+                    v = gelu_erf(v);
+                    if (do_round) v = round_bf16(v);
+                }
+                stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * EP + j * 32 + lr] = v;
+            }
+        }
+        // same wave wrote and now reads: LDS operations of a wave complete in order
+        const int row_base = bm0 + wm * 64 + i * 32, col_base = bn0 + wn * 64;
+        if (g.out_dtype == ACAI_BF16) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = it * 64 + lane, r = idx >> 3, c8 = (idx & 7) * 8;
+                const int row = row_base + r;
+                if (row < g.M && c8 < n_valid) {
+                    f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c8), v1 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c8 + 4);
+                    if (g.residual) {
+                        const float *rp = g.residual + (size_t)row * g.ldr + col_base + c8;
+                        const f32x4 r0 = *reinterpret_cast<const f32x4 *>(rp), r1 = *reinterpret_cast<const f32x4 *>(rp + 4);
+                        v0 += r0;
+                        v1 += r1;
+                    }
+                    uint4 o;
+                    o.x = pack_bf16(v0[0], v0[1]); o.y = pack_bf16(v0[2], v0[3]); o.z = pack_bf16(v1[0], v1[1]); o.w = pack_bf16(v1[2], v1[3]);
+                    *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(g.C) + (size_t)row * ldc_e + col_base + c8) = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = it * 64 + lane, r = idx >> 4, c4 = (idx & 15) * 4;
+                const int row = row_base + r;
+                if (row < g.M && c4 < n_valid) {
+                    f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c4);
+                    if (g.residual) v0 += *reinterpret_cast<const f32x4 *>(g.residual + (size_t)row * g.ldr + col_base + c4);
+                    *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)row * ldc_e + col_base + c4) = v0;
+                }
+            }
+        }
+    }
 }
 
 template <typename T, int EPI, bool TA = false, bool TB = false>
@@ -361,6 +424,7 @@ int launch(const GemmArgs &g, hipStream_t st) {
         h.ksplit = ks;
         nwg *= ks;
     }
+    h.vec_epi = (EPI == 0) && (g.ldc % 8 == 0) && (g.N % 8 == 0) && aligned16(g.C) && (!g.residual || (g.ldr % 4 == 0 && aligned16(g.residual)));
     constexpr int BKG = ROWB / (int)sizeof(T);
     static const bool no_glds = getenv("ACAI_GEMM_NO_GLDS") != nullptr;
     if (fast && !TA && !TB && g.K % BKG == 0 && !no_glds)
