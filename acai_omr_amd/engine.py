@@ -39,6 +39,16 @@ class WeightCache:
             return p.detach()
         return self._get(p, "w16", lambda t: t.to(torch.bfloat16).contiguous())
 
+    def wt(self, p, prec):
+        """Transposed operand copy [in_features, out_features] in the compute dtype: turns dX = dY . W into the row-major
+        (direct-to-LDS) GEMM form; refreshed when the parameter changes (once per optimizer step)."""
+        dt = torch.bfloat16 if prec == "bf16" else torch.float32
+        def make(t):
+            out = torch.empty((t.shape[1], t.shape[0]), dtype=dt, device=t.device)  # fresh row-major strides even for size-1 dims
+            out.copy_(t.t())
+            return out
+        return self._get(p, "wt" + prec, make)
+
     def b(self, p, prec):
         if p is None:
             return None

@@ -36,6 +36,11 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def _ld(t):
+    """Row stride of a 2-D tensor whose last dim is contiguous; a single-row tensor reports an arbitrary stride(0)."""
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
 def layernorm(x, w, b, eps, want_f32=True, want_bf16=False, out_f32=None):
     _chk(x, "x", torch.float32)
     assert x.is_contiguous() and x.dim() == 2
@@ -62,8 +67,8 @@ def gemm_nt(a, w, bias=None, residual=None, out_dtype=torch.float32, gelu=False,
     if residual is not None:
         assert residual.dtype == torch.float32 and residual.shape == (M, N) and residual.stride(1) == 1
     flags = (GEMM_GELU if gelu else 0) | (GEMM_ROUND_BF16 if round_bf16 else 0)
-    _lib.check(_lib.lib().acai_gemm_nt(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _p(bias), _p(residual),
-                                       residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0),
+    _lib.check(_lib.lib().acai_gemm_nt(a.data_ptr(), _ld(a), w.data_ptr(), _ld(w), _p(bias), _p(residual),
+                                       _ld(residual) if residual is not None else 0, out.data_ptr(), _ld(out),
                                        M, N, K, _dt(a), _dt(out), flags, _st()), "acai_gemm_nt")
     return out
 
@@ -81,8 +86,8 @@ def gemm(a, w, trans_a=False, trans_w=False, bias=None, residual=None, out_dtype
     assert out.shape == (M, N) and out.stride(1) == 1
     if residual is not None:
         assert residual.dtype == torch.float32 and residual.shape == (M, N) and residual.stride(1) == 1
-    _lib.check(_lib.lib().acai_gemm(a.data_ptr(), a.stride(0), 1 if trans_a else 0, w.data_ptr(), w.stride(0), 1 if trans_w else 0, _p(bias),
-                                    _p(residual), residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0), M, N, K,
+    _lib.check(_lib.lib().acai_gemm(a.data_ptr(), _ld(a), 1 if trans_a else 0, w.data_ptr(), _ld(w), 1 if trans_w else 0, _p(bias),
+                                    _p(residual), _ld(residual) if residual is not None else 0, out.data_ptr(), _ld(out), M, N, K,
                                     _dt(a), _dt(out), 0, _st()), "acai_gemm")
     return out
 

@@ -60,8 +60,7 @@ class LinearFn(Function):
             dyc = ops.cast_bf16(dy)
         elif not bf and dy.dtype != torch.float32:
             dyc = dy.float()
-        Wc = ctx.wc.w(W, prec)
-        dx = ops.gemm(dyc, Wc, trans_w=True, out_dtype=x.dtype) if ctx.needs_input_grad[0] else None
+        dx = ops.gemm_nt(dyc, ctx.wc.wt(W, prec), out_dtype=x.dtype) if ctx.needs_input_grad[0] else None
         dW = ops.gemm(dyc, x, trans_a=True, trans_w=True, out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
         db = ops.colsum(dyc) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dW, db, dres, None, None, None
@@ -480,6 +479,9 @@ class _SliceCache:
 
     def w(self, _p, prec):
         return self.wc.w(self.attn.in_proj_weight, prec)[self.r0:self.r1]
+
+    def wt(self, _p, prec):
+        return self.wc.wt(self.attn.in_proj_weight, prec)[:, self.r0:self.r1]
 
     def b(self, _p, prec):
         return None if _p is None else self.wc.b(self.attn.in_proj_bias, prec)[self.r0:self.r1]
