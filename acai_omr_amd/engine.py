@@ -322,13 +322,13 @@ class DecodeEngine:
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
             self.arm(self.B)
-            g = self.ensure_graph()
+            self.ensure_graph(1)
+            self.arm(self.B)
         done, total = 0, max_len - 1
         while done < total:
             n = min(chunk, total - done)
             with torch.cuda.stream(self.stream):
-                for _ in range(n):
-                    g.launch()
+                self.launch_steps(n)
                 fin = int(self.finished[self.B].item()) == 0
             cur.wait_stream(self.stream)
             done += n
@@ -346,10 +346,12 @@ class DecodeEngine:
         self.reset_self_cache()
         self.step.copy_(torch.tensor([1, 0], dtype=torch.int32))
 
-    def ensure_graph(self):
-        """hipGraph of one decode step for the current (B, cross split) configuration.  Must run on self.stream."""
+    STEPS_PER_GRAPH = 8   # a graph replay costs ~10-15 us of launch latency: amortise it over several decode steps
+
+    def ensure_graph(self, nsteps=1):
+        """hipGraph of `nsteps` consecutive decode steps for the current (B, cross split) configuration.  Must run on self.stream."""
         B = self.B
-        key = (B, self.cross_nsplit)
+        key = (B, self.cross_nsplit, nsteps)
         g = self.graphs.get(key)
         if g is None:
             st = ops._st()
@@ -361,26 +363,40 @@ class DecodeEngine:
             g = ops.Graph()
             g.begin()
             try:
-                _lib.check(_lib.lib().acai_decode_step(ctypes.byref(self._desc), st), "acai_decode_step")
+                for _ in range(nsteps):
+                    _lib.check(_lib.lib().acai_decode_step(ctypes.byref(self._desc), st), "acai_decode_step")
             finally:
                 g.end()
             self.graphs[key] = g
         return g
 
+    def launch_steps(self, n, use_graph=True):
+        """Enqueue n decode steps on the current stream (graphs of STEPS_PER_GRAPH steps + single-step graphs for the rest)."""
+        if not use_graph:
+            st = ops._st()
+            for _ in range(n):
+                _lib.check(_lib.lib().acai_decode_step(ctypes.byref(self._desc), st), "acai_decode_step")
+            return
+        big = self.STEPS_PER_GRAPH
+        while n >= big:
+            self.ensure_graph(big).launch()
+            n -= big
+        while n > 0:
+            self.ensure_graph(1).launch()
+            n -= 1
+
     def _greedy_on_stream(self, max_len, poll, use_graph, on_chunk):
         B = self.B
         self.arm(B)
-        st = ops._st()
-        if use_graph:
-            launch = self.ensure_graph().launch
-        else:
-            launch = lambda: _lib.check(_lib.lib().acai_decode_step(ctypes.byref(self._desc), st), "acai_decode_step")  # noqa: E731
+        if use_graph:   # capture (and warm up) before the loop, then re-arm: the warm-up launch advances the device state
+            self.ensure_graph(1)
+            self.ensure_graph(self.STEPS_PER_GRAPH)
+            self.arm(B)
         done = 0
         total = max_len - 1
         while done < total:
             n = min(poll, total - done)
-            for _ in range(n):
-                launch()
+            self.launch_steps(n, use_graph)
             done += n
             self.cache_len = done
             if on_chunk is not None:

@@ -163,12 +163,17 @@ def main():
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    local = local % max(1, torch.cuda.device_count())   # (rehearsals may put several ranks on one card)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)   # RCCL; used for the barrier / max-reduce of the timing only
+        backend = os.environ.get("ACAI_BENCH_BACKEND", "nccl")   # "nccl" is RCCL over xGMI on ROCm; "gloo" only for single-card rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from torch.amp import autocast
     vitomr = build_model(dev, a.batch)
@@ -198,16 +203,16 @@ def main():
     eng.stream.wait_stream(cur)
     with torch.cuda.stream(eng.stream):
         eng.arm(eng.B)
-        graph = eng.ensure_graph()
-        for _ in range(a.warmup):
-            graph.launch()
+        eng.ensure_graph(1)
+        eng.ensure_graph(eng.STEPS_PER_GRAPH)
+        eng.arm(eng.B)
+        eng.launch_steps(a.warmup)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
-            graph.launch()
+        eng.launch_steps(a.steps)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -223,7 +228,6 @@ def main():
 
     mae_res = None
     if not a.no_mae:
-        del graph
         mae_res = bench_mae(dev, rank, world, dist, a.mae_batch, a.height, a.width, a.mae_steps, a.mae_dtype)
 
     out = None
