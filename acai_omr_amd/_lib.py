@@ -7,7 +7,7 @@ without a GPU); the built .so is git-ignored but travels to the GPU box with the
 import ctypes
 import os
 import subprocess
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libacai_omr_hip.so")
@@ -46,10 +46,11 @@ _SIGNATURES = {
     "acai_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "acai_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "acai_attn_varlen_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
-                                     c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+                                     c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_uint32, c_void_p]),
     "acai_attn_varlen_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                                      c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                     c_int, c_int, c_int, c_void_p]),
+                                     c_int, c_int, c_int, c_float, c_uint32, c_void_p]),
+    "acai_dropout_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_uint32, c_int, c_int, c_void_p]),
     "acai_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "acai_gelu_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "acai_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),

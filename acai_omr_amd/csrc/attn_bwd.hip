@@ -25,6 +25,8 @@ struct BwdArgs {
     const int32_t *cu_q, *cu_k;
     int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, H, dh, causal, total_q;
     float scale_log2e, scale;
+    uint32_t drop_thr, drop_seed;  // the forward's attention-probability dropout, regenerated element-wise
+    float drop_scale;
 };
 
 template <typename T, bool FAST>
@@ -177,6 +179,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
             for (int e = 0; e < 16; ++e) sacc[e] = dpacc[e] = 0.f;
             mma_rows<T, NS>(sacc, ldsK + kb * 32 * RP, RP, lr, lh, qf);     // S^T[key][q]
             mma_rows<T, NS>(dpacc, ldsV + kb * 32 * RP, RP, lr, lh, dof);   // dP^T[key][q]
+            if (a.drop_thr) {  // dP = mask/(1-p) o (dO V^T)
+                const uint32_t rrow = (uint32_t)(h * a.total_q + q_start + my_q);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t key = (uint32_t)(kt * TT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh);
+                    dpacc[e] = drop_keep(a.drop_seed, rrow, key, a.drop_thr) ? dpacc[e] * a.drop_scale : 0.f;
+                }
+            }
             if (interior) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) sacc[e] = fast_exp2(fmaf(sacc[e], a.scale_log2e, -lse)) * (dpacc[e] - dlt);   // dS^T
@@ -276,7 +286,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
             }
             // interior: every query of the tile exists, every key of the WAVE exists and (causal) lies at or before the tile's first query
             const bool interior = (qt + 1) * TT <= lq && k0 + wave * 32 + 32 <= lk && (!a.causal || k0 + wave * 32 + 31 <= qt * TT + qb * 32);
-            if (interior) {
+            if (a.drop_thr) {  // keep mask of (query row, my key): dP is masked, and so is the P that multiplies dO for dV
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ql = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, qq = qt * TT + ql;
+                    const bool ok = qq < lq && my_k < lk && (!a.causal || my_k <= qq);
+                    const float p = ok ? fast_exp2(sacc[e] * a.scale_log2e - lse4[e >> 2][e & 3]) : 0.f;
+                    const float mk = drop_keep(a.drop_seed, (uint32_t)(h * a.total_q + q_start + qq), (uint32_t)my_k, a.drop_thr) ? a.drop_scale : 0.f;
+                    sacc[e] = p * mk;                                                  // dropped P (for dV)
+                    dpacc[e] = p * (dpacc[e] * mk - dlt4[e >> 2][e & 3]);              // dS
+                }
+            } else if (interior) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const float p = fast_exp2(fmaf(sacc[e], a.scale_log2e, -lse4[e >> 2][e & 3]));
@@ -356,7 +376,7 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, hipStream_t st) {
 extern "C" int acai_attn_varlen_bwd(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, const void *o, int ldo,
                                     const void *dout, int lddo, void *dq, int lddq, void *dk, int lddk, void *dv, int lddv, const float *lse,
                                     float *delta, const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int max_k,
-                                    int total_q, int causal, int dtype, void *stream) {
+                                    int total_q, int causal, int dtype, float dropout_p, uint32_t dropout_seed, void *stream) {
     ACAI_CHECK_ARG(q && k && v && o && dout && dq && dk && dv && lse && delta && cu_q && cu_k, "acai_attn_varlen_bwd: null operand");
     ACAI_CHECK_ARG(B > 0 && H > 0 && dh > 0 && dh <= 64 && max_q > 0 && max_k > 0 && total_q > 0 && B <= 65535 && H <= 65535,
                    "acai_attn_varlen_bwd: bad dims");
@@ -364,6 +384,8 @@ extern "C" int acai_attn_varlen_bwd(const void *q, int ldq, const void *k, int l
     a.q = q; a.k = k; a.v = v; a.o = o; a.dout = dout; a.dq = dq; a.dk = dk; a.dv = dv; a.lse = lse; a.delta = delta; a.cu_q = cu_q; a.cu_k = cu_k;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
     a.H = H; a.dh = dh; a.causal = causal; a.total_q = total_q;
+    ACAI_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "acai_attn_varlen_bwd: dropout_p out of range");
+    a.drop_thr = (uint32_t)((double)dropout_p * 4294967296.0); a.drop_seed = dropout_seed; a.drop_scale = 1.0f / (1.0f - dropout_p);
     a.scale = 1.0f / sqrtf((float)dh);
     a.scale_log2e = 1.4426950408889634f * a.scale;
     hipStream_t st = (hipStream_t)stream;

@@ -27,6 +27,8 @@ struct AttnArgs {
     const int32_t *cu_q, *cu_k;
     int ldq, ldk, ldv, ldo, H, dh, causal;
     float scale_log2e;
+    uint32_t drop_thr, drop_seed;  // attention-probability dropout (nn.MultiheadAttention(dropout=p) in train mode): keep iff hash >= thr
+    float drop_scale;
     float *lse;   // optional [H][total_q]: log2-domain log-sum-exp of the scaled scores (saved for the backward pass)
     int total_q;
 };
@@ -187,6 +189,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 }
         }
         l_run = l_run * alpha + psum;
+        if (a.drop_thr) {  // the normaliser uses the undropped probabilities; only the P that multiplies V is masked and rescaled
+            const uint32_t rrow = (uint32_t)(h * a.total_q + q_start + my_q);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t key = (uint32_t)(kt * KT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh);
+                    sacc[kb][e] = drop_keep(a.drop_seed, rrow, key, a.drop_thr) ? sacc[kb][e] * a.drop_scale : 0.f;
+                }
+        }
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
 #pragma unroll
@@ -290,12 +302,14 @@ int launch(const AttnArgs &a, int B, int max_q, hipStream_t st) {
 
 extern "C" int acai_attn_varlen_fwd(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, void *out, int ldo,
                                     const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int causal,
-                                    int dtype, float *lse, int total_q, void *stream) {
+                                    int dtype, float *lse, int total_q, float dropout_p, uint32_t dropout_seed, void *stream) {
     ACAI_CHECK_ARG(q && k && v && out && cu_q && cu_k, "acai_attn_varlen_fwd: null operand");
     ACAI_CHECK_ARG(B > 0 && H > 0 && dh > 0 && dh <= 64 && max_q > 0, "acai_attn_varlen_fwd: bad dims B=%d H=%d dh=%d max_q=%d (dh <= 64)", B, H, dh, max_q);
     ACAI_CHECK_ARG(ldq >= H * dh && ldk >= H * dh && ldv >= H * dh && ldo >= H * dh, "acai_attn_varlen_fwd: row stride smaller than H*dh");
     ACAI_CHECK_ARG(B <= 65535 && H <= 65535, "acai_attn_varlen_fwd: grid too large");
-    AttnArgs a{q, k, v, out, cu_q, cu_k, ldq, ldk, ldv, ldo, H, dh, causal, 0.f, lse, total_q};
+    ACAI_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "acai_attn_varlen_fwd: dropout_p out of range");
+    AttnArgs a{q, k, v, out, cu_q, cu_k, ldq, ldk, ldv, ldo, H, dh, causal, 0.f, (uint32_t)((double)dropout_p * 4294967296.0), dropout_seed,
+               1.0f / (1.0f - dropout_p), lse, total_q};
     a.scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == ACAI_BF16) return dh <= 32 ? launch<bf16_t, 32>(a, B, max_q, st) : launch<bf16_t, 64>(a, B, max_q, st);

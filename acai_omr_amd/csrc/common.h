@@ -40,6 +40,18 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) { return (uint
 // results below 2^-126 may flush to zero)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Counter-based dropout RNG: a 32-bit avalanche hash of (seed, row, col), so that any kernel can regenerate the keep mask of an
+// element in any thread layout (forward: key rows in registers; dK/dV backward: query rows in registers).  ~10 integer ops / element.
+__device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t row, uint32_t col) {
+    uint32_t x = (row * 0x9E3779B1u) ^ (col * 0x85EBCA77u) ^ seed;
+    x ^= x >> 15; x *= 0x2C1B3C6Du;
+    x ^= x >> 12; x *= 0x297A2D39u;
+    x ^= x >> 15;
+    return x;
+}
+// keep probability 1 - p as a 32-bit threshold: keep iff hash >= thr
+__device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t row, uint32_t col, uint32_t thr) { return drop_hash(seed, row, col) >= thr; }
+
 // exact-erf GELU, as torch's F.gelu(approximate="none")
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

@@ -159,6 +159,20 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float *__restrict__ 
     if (lane == 0) atomicAdd(loss, (lse - lg[tg]) * inv_count);
 }
 
+// out = residual + keep(row, col) * x / (1 - p)   (nn.Dropout after a projection, then the residual add; also its own backward:
+// call it on dy with residual = NULL).  x in T, residual / out fp32 or T.
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void dropout_add_kernel(const T *__restrict__ x, const float *__restrict__ res, TO *out, int rows, int cols,
+                                                          uint32_t thr, float scale, uint32_t seed) {
+    const long n = (long)rows * cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+        float v = drop_keep(seed, (uint32_t)r, (uint32_t)c, thr) ? DT<T>::ld(x + i) * scale : 0.f;
+        if (res) v += res[i];
+        DT<TO>::st(out + i, v);
+    }
+}
+
 static inline int grid1d(long n) {
     long g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -234,5 +248,25 @@ extern "C" int acai_ce_loss(const float *logits, int ld, const int64_t *target, 
     if (rows == 0) return 0;
     hipLaunchKernelGGL(ce_loss_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits, ld, target, ignore_index, inv_count, loss, dlogits, rows, V);
     ACAI_LAUNCH_CHECK("acai_ce_loss");
+    return 0;
+}
+
+extern "C" int acai_dropout_add(const void *x, const float *residual, void *out, int rows, int cols, float p, uint32_t seed, int x_dtype,
+                                int out_dtype, void *stream) {
+    ACAI_CHECK_ARG(x && out && rows >= 0 && cols > 0 && p >= 0.f && p < 1.f, "acai_dropout_add: bad arguments");
+    if (rows == 0) return 0;
+    const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+    const float scale = 1.0f / (1.0f - p);
+    const long n = (long)rows * cols;
+    hipStream_t st = (hipStream_t)stream;
+    if (x_dtype == ACAI_BF16 && out_dtype == ACAI_BF16)
+        hipLaunchKernelGGL((dropout_add_kernel<bf16_t, bf16_t>), dim3(grid1d(n)), dim3(256), 0, st, (const bf16_t *)x, residual, (bf16_t *)out, rows, cols, thr, scale, seed);
+    else if (x_dtype == ACAI_BF16)
+        hipLaunchKernelGGL((dropout_add_kernel<bf16_t, float>), dim3(grid1d(n)), dim3(256), 0, st, (const bf16_t *)x, residual, (float *)out, rows, cols, thr, scale, seed);
+    else if (out_dtype == ACAI_BF16)
+        hipLaunchKernelGGL((dropout_add_kernel<float, bf16_t>), dim3(grid1d(n)), dim3(256), 0, st, (const float *)x, residual, (bf16_t *)out, rows, cols, thr, scale, seed);
+    else
+        hipLaunchKernelGGL((dropout_add_kernel<float, float>), dim3(grid1d(n)), dim3(256), 0, st, (const float *)x, residual, (float *)out, rows, cols, thr, scale, seed);
+    ACAI_LAUNCH_CHECK("acai_dropout_add");
     return 0;
 }

@@ -124,7 +124,7 @@ def gather_rows(table, idx, add=None, out=None):
     return out
 
 
-def attn_varlen(q, k, v, cu_q, cu_k, H, dh, max_q, causal=False, out=None, lse=None):
+def attn_varlen(q, k, v, cu_q, cu_k, H, dh, max_q, causal=False, out=None, lse=None, dropout_p=0.0, seed=0):
     """q [Mq, >=H*dh], k/v [Mk, >=H*dh] (2-D views with any row stride), cu_* int32 [B+1] on the GPU."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _chk(t, n)
@@ -137,7 +137,8 @@ def attn_varlen(q, k, v, cu_q, cu_k, H, dh, max_q, causal=False, out=None, lse=N
     assert out.shape[0] == q.shape[0] and out.stride(1) == 1 and out.dtype == q.dtype
     _lib.check(_lib.lib().acai_attn_varlen_fwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
                                                out.data_ptr(), out.stride(0), cu_q.data_ptr(), cu_k.data_ptr(), B, H, dh, int(max_q),
-                                               1 if causal else 0, _dt(q), _p(lse), q.shape[0], _st()), "acai_attn_varlen_fwd")
+                                               1 if causal else 0, _dt(q), _p(lse), q.shape[0], float(dropout_p), int(seed) & 0xFFFFFFFF, _st()),
+               "acai_attn_varlen_fwd")
     return out
 
 
@@ -199,7 +200,7 @@ def decode_attn(q, kc, vc, seq_off, seq_len, H, dh, dhp, max_len, round_out=Fals
     return out
 
 
-def attn_varlen_bwd(q, k, v, o, dout, lse, cu_q, cu_k, H, dh, max_q, max_k, causal, dq, dk, dv):
+def attn_varlen_bwd(q, k, v, o, dout, lse, cu_q, cu_k, H, dh, max_q, max_k, causal, dq, dk, dv, dropout_p=0.0, seed=0):
     """Gradients of attn_varlen w.r.t. q, k, v, written into the (strided) views dq, dk, dv."""
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (dout, "dout"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
         _chk(t, n)
@@ -212,7 +213,20 @@ def attn_varlen_bwd(q, k, v, o, dout, lse, cu_q, cu_k, H, dh, max_q, max_k, caus
     _lib.check(_lib.lib().acai_attn_varlen_bwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), o.data_ptr(), o.stride(0),
                                                dout.data_ptr(), dout.stride(0), dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(),
                                                dv.stride(0), lse.data_ptr(), delta.data_ptr(), cu_q.data_ptr(), cu_k.data_ptr(), B, H, dh, int(max_q),
-                                               int(max_k), total_q, 1 if causal else 0, _dt(q), _st()), "acai_attn_varlen_bwd")
+                                               int(max_k), total_q, 1 if causal else 0, _dt(q), float(dropout_p), int(seed) & 0xFFFFFFFF, _st()),
+               "acai_attn_varlen_bwd")
+
+
+def dropout_add(x, residual, p, seed, out_dtype=None):
+    """out = residual + keep * x / (1 - p) (residual fp32 or None); the mask depends only on (seed, row, col)."""
+    _chk(x, "x")
+    assert x.dim() == 2 and x.is_contiguous()
+    out = torch.empty(x.shape, dtype=out_dtype or (torch.float32 if residual is not None else x.dtype), device=x.device)
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.shape == x.shape and residual.is_contiguous()
+    _lib.check(_lib.lib().acai_dropout_add(x.data_ptr(), _p(residual), out.data_ptr(), x.shape[0], x.shape[1], float(p), int(seed) & 0xFFFFFFFF,
+                                           _dt(x), _dt(out), _st()), "acai_dropout_add")
+    return out
 
 
 def layernorm_bwd(x, w, dy, eps, want_param_grads=True):

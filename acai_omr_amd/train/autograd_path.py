@@ -8,7 +8,8 @@ differentiable row gather (`pad_rows`).
 Step semantics reproduced: MAE pre-training runs fp32 outside autocast
 (acai_omr/train/pre_train.py:54-62); the teacher-forced step runs its forward under autocast(bfloat16)
 (acai_omr/train/omr_teacher_force_train.py:113-120) - precision follows `torch.is_autocast_enabled("cuda")` exactly as in
-the inference path.  Dropout > 0 in train mode is not built yet (the parity configs use p = 0) and raises.
+the inference path.  Dropout (train mode) is a counter-based hash mask regenerated in backward: residual dropouts through
+`acai_dropout_add`, attention-probability dropout inside the flash kernels; seeds come from torch's CPU generator.
 """
 import torch
 from torch.autograd import Function
@@ -26,13 +27,21 @@ def _cdt(prec):
     return torch.bfloat16 if prec == "bf16" else torch.float32
 
 
+def _p_of(module, training):
+    """Dropout probability of an nn.Dropout / nn.MultiheadAttention in train mode (0 in eval)."""
+    if not training or module is None:
+        return 0.0
+    p = module.p if isinstance(module, torch.nn.Dropout) else getattr(module, "dropout", 0.0)
+    return float(p)
+
+
+def _next_seed():
+    """Seeds of the counter-based dropout masks come from torch's CPU generator: torch.manual_seed() makes a step reproducible."""
+    return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+
+
 def _check_dropout(module):
-    if module.training:
-        for m in module.modules():
-            p = getattr(m, "p", None) if isinstance(m, torch.nn.Dropout) else getattr(m, "dropout", None) if isinstance(m, torch.nn.MultiheadAttention) else None
-            if isinstance(p, float) and p > 0.0:
-                raise NotImplementedError("acai_omr_amd: dropout > 0 in train mode is not built in the HIP training path yet; construct the model "
-                                          "with dropout 0.0 (as the parity configs do) or call .eval()")
+    return None  # dropout is built: see DropoutAddFn and the attention kernels' dropout_p
 
 
 # ---- autograd Functions ---------------------------------------------------------------------------------------------------
@@ -70,48 +79,74 @@ class SelfAttnFn(Function):
     """Packed self attention on a fused qkv tensor [M, 3E] -> [M, E]."""
 
     @staticmethod
-    def forward(ctx, qkv, cu, H, dh, max_len, causal):
+    def forward(ctx, qkv, cu, H, dh, max_len, causal, dropout_p=0.0):
         E = H * dh
         M = qkv.shape[0]
         lse = torch.empty(H * M, dtype=torch.float32, device=qkv.device)
-        out = ops.attn_varlen(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], cu, cu, H, dh, max_len, causal=causal, lse=lse)
+        seed = _next_seed() if dropout_p > 0 else 0
+        out = ops.attn_varlen(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], cu, cu, H, dh, max_len, causal=causal, lse=lse, dropout_p=dropout_p, seed=seed)
         ctx.save_for_backward(qkv, out, lse, cu)
-        ctx.cfg = (H, dh, max_len, causal)
+        ctx.cfg = (H, dh, max_len, causal, dropout_p, seed)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, out, lse, cu = ctx.saved_tensors
-        H, dh, max_len, causal = ctx.cfg
+        H, dh, max_len, causal, dropout_p, seed = ctx.cfg
         E = H * dh
         dqkv = torch.empty_like(qkv)
         dout = dout.contiguous().to(qkv.dtype)
         ops.attn_varlen_bwd(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], out, dout, lse, cu, cu, H, dh, max_len, max_len, causal,
-                            dqkv[:, :E], dqkv[:, E:2 * E], dqkv[:, 2 * E:])
-        return dqkv, None, None, None, None, None
+                            dqkv[:, :E], dqkv[:, E:2 * E], dqkv[:, 2 * E:], dropout_p=dropout_p, seed=seed)
+        return dqkv, None, None, None, None, None, None
 
 
 class CrossAttnFn(Function):
     """Packed cross attention: q [Mq, E], kv [Mk, 2E] -> [Mq, E]."""
 
     @staticmethod
-    def forward(ctx, q, kv, cu_q, cu_k, H, dh, max_q, max_k):
+    def forward(ctx, q, kv, cu_q, cu_k, H, dh, max_q, max_k, dropout_p=0.0):
         E = H * dh
         lse = torch.empty(H * q.shape[0], dtype=torch.float32, device=q.device)
-        out = ops.attn_varlen(q, kv[:, :E], kv[:, E:], cu_q, cu_k, H, dh, max_q, lse=lse)
+        seed = _next_seed() if dropout_p > 0 else 0
+        out = ops.attn_varlen(q, kv[:, :E], kv[:, E:], cu_q, cu_k, H, dh, max_q, lse=lse, dropout_p=dropout_p, seed=seed)
         ctx.save_for_backward(q, kv, out, lse, cu_q, cu_k)
-        ctx.cfg = (H, dh, max_q, max_k)
+        ctx.cfg = (H, dh, max_q, max_k, dropout_p, seed)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, kv, out, lse, cu_q, cu_k = ctx.saved_tensors
-        H, dh, max_q, max_k = ctx.cfg
+        H, dh, max_q, max_k, dropout_p, seed = ctx.cfg
         E = H * dh
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
         ops.attn_varlen_bwd(q, kv[:, :E], kv[:, E:], out, dout.contiguous().to(q.dtype), lse, cu_q, cu_k, H, dh, max_q, max_k, False,
-                            dq, dkv[:, :E], dkv[:, E:])
-        return dq, dkv, None, None, None, None, None, None
+                            dq, dkv[:, :E], dkv[:, E:], dropout_p=dropout_p, seed=seed)
+        return dq, dkv, None, None, None, None, None, None, None
+
+
+class DropoutAddFn(Function):
+    """out = residual + dropout_p(x) (residual may be None).  The mask is regenerated from the seed in backward (nothing is stored)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, p, seed):
+        ctx.cfg = (p, seed, x.dtype, residual is not None)
+        return ops.dropout_add(x.contiguous(), residual, p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, xdt, has_res = ctx.cfg
+        dy = dy.contiguous()
+        dx = ops.dropout_add(dy, None, p, seed, out_dtype=xdt)
+        return dx, (dy if has_res else None), None, None
+
+
+def _proj_residual(x, lin_w, lin_b, residual, p, prec, wc):
+    """residual + dropout_p(Linear(x)): fused into the GEMM epilogue when p == 0."""
+    if p <= 0.0:
+        return LinearFn.apply(x, lin_w, lin_b, residual, prec, wc, True)
+    y = LinearFn.apply(x, lin_w, lin_b, None, prec, wc, False)
+    return DropoutAddFn.apply(y, residual, p, _next_seed())
 
 
 class LayerNormFn(Function):
@@ -202,18 +237,22 @@ def _lin(x32, lin_w, lin_b, prec, wc, residual=None, out_fp32=False):
     return LinearFn.apply(x, lin_w, lin_b, residual, prec, wc, out_fp32)
 
 
-def encoder_stack(stack, x32, cu, max_len, H, prec, wc):
+def encoder_stack(stack, x32, cu, max_len, H, prec, wc, training=False):
+    """Post-LN blocks with the dropout sites of torch's TransformerEncoderLayer (attention probabilities, dropout1 after the
+    out-projection, dropout after the activation, dropout2 after linear2) active when `training`."""
     E = x32.shape[1]
     dh = E // H
     for layer in stack.layers:
         sa = layer.self_attn
         qkv = _lin(x32, sa.in_proj_weight, sa.in_proj_bias, prec, wc)
-        attn = SelfAttnFn.apply(qkv, cu, H, dh, max_len, False)
-        y = LinearFn.apply(attn, sa.out_proj.weight, sa.out_proj.bias, x32, prec, wc, True)
+        attn = SelfAttnFn.apply(qkv, cu, H, dh, max_len, False, _p_of(sa, training))
+        y = _proj_residual(attn, sa.out_proj.weight, sa.out_proj.bias, x32, _p_of(layer.dropout1, training), prec, wc)
         x32 = LayerNormFn.apply(y, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
         a = _lin(x32, layer.linear1.weight, layer.linear1.bias, prec, wc)
         h = GeluFn.apply(a)
-        y = LinearFn.apply(h, layer.linear2.weight, layer.linear2.bias, x32, prec, wc, True)
+        if _p_of(layer.dropout, training) > 0:
+            h = DropoutAddFn.apply(h, None, _p_of(layer.dropout, training), _next_seed())
+        y = _proj_residual(h, layer.linear2.weight, layer.linear2.bias, x32, _p_of(layer.dropout2, training), prec, wc)
         x32 = LayerNormFn.apply(y, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
     if stack.norm is not None:
         x32 = LayerNormFn.apply(x32, stack.norm.weight, stack.norm.bias, stack.norm.eps)
@@ -268,7 +307,7 @@ def encoder_forward_packed(enc, x):
     x32 = LinearFn.apply(patches, enc.projection.weight, enc.projection.bias, pe, prec, wc, True)
     cu = EG.cu_from_lens(lens, x32.device)
     for st in enc._stacks():
-        x32 = encoder_stack(st, x32, cu, max(lens), enc._num_heads(), prec, wc)
+        x32 = encoder_stack(st, x32, cu, max(lens), enc._num_heads(), prec, wc, training=enc.training)
     return x32, None, lens
 
 
@@ -279,6 +318,8 @@ def head_forward(head, x):
     x2 = x.reshape(-1, shp[-1]).float()
     a = _lin(x2, head[0].weight, head[0].bias, prec, wc)
     h = GeluFn.apply(a)
+    if _p_of(head[2], head.training) > 0:
+        h = DropoutAddFn.apply(h, None, _p_of(head[2], head.training), _next_seed())
     y = LinearFn.apply(h, head[3].weight, head[3].bias, None, prec, wc, False)
     return y.view(*shp[:-1], y.shape[-1])
 
@@ -308,7 +349,7 @@ def _mae_encode(mae, imgs, dims, keep, kept, prec):
     pe = _pe_rows(enc, enc.pos_embedding, dims, select=keep)
     x32 = LinearFn.apply(patches, enc.projection.weight, enc.projection.bias, pe, prec, wc, True)
     cu = EG.cu_from_lens(kept, x32.device)
-    return encoder_stack(enc.encoder_blocks, x32, cu, max(kept), enc._num_heads(), prec, wc)
+    return encoder_stack(enc.encoder_blocks, x32, cu, max(kept), enc._num_heads(), prec, wc, training=enc.training)
 
 
 def mae_encoder_forward(enc, x, noises=None):
@@ -332,7 +373,7 @@ def mae_decoder_forward(dec, x, attention_mask):
     packed, lens = unpad_rows(x, attention_mask)
     cu = EG.cu_from_lens(lens, packed.device)
     H = dec.decoder_blocks.layers[0].self_attn.num_heads
-    y = encoder_stack(dec.decoder_blocks, packed, cu, max(lens), H, _prec(), _wc(dec))
+    y = encoder_stack(dec.decoder_blocks, packed, cu, max(lens), H, _prec(), _wc(dec), training=dec.training)
     return pad_rows(y, lens)[0]
 
 
@@ -361,7 +402,7 @@ def mae_forward(mae, batch, noises=None, packed=False):
     x32 = GatherRowsFn.apply(table, torch.cat(idx).to(dev), dpe)
     cu = EG.cu_from_lens(lens, dev)
     H = mae.decoder.decoder_blocks.layers[0].self_attn.num_heads
-    x32 = encoder_stack(mae.decoder.decoder_blocks, x32, cu, max(lens), H, prec, _wc(mae.decoder))
+    x32 = encoder_stack(mae.decoder.decoder_blocks, x32, cu, max(lens), H, prec, _wc(mae.decoder), training=mae.training)
     pred = _lin(x32, mae.decoder_unembed.weight, mae.decoder_unembed.bias, prec, wc, out_fp32=True)
     # targets and loss mask (no gradient)
     from ..models.models import _as_image_list
@@ -449,19 +490,22 @@ def decoder_forward(dec, input_seqs, img_latent, lmx_attention_mask, latent_atte
     mt, ms = max(lens_t), max(lens_s)
     for ly in dec.decoder_blocks.layers:
         sa, ca = ly.self_attn, ly.multihead_attn
+        tr = dec.training
         qkv = _lin(x32, sa.in_proj_weight, sa.in_proj_bias, prec, wc)
-        a = SelfAttnFn.apply(qkv, cu_t, H, dh, mt, True)
-        y = LinearFn.apply(a, sa.out_proj.weight, sa.out_proj.bias, x32, prec, wc, True)
+        a = SelfAttnFn.apply(qkv, cu_t, H, dh, mt, True, _p_of(sa, tr))
+        y = _proj_residual(a, sa.out_proj.weight, sa.out_proj.bias, x32, _p_of(ly.dropout1, tr), prec, wc)
         x32 = LayerNormFn.apply(y, ly.norm1.weight, ly.norm1.bias, ly.norm1.eps)
         xc = CastBf16Fn.apply(x32) if bf else x32
         q = LinearFn.apply(xc, ca.in_proj_weight[:E], ca.in_proj_bias[:E], None, prec, _SliceCache(wc, ca, 0, E), False)
         kv = LinearFn.apply(memc, ca.in_proj_weight[E:], ca.in_proj_bias[E:], None, prec, _SliceCache(wc, ca, E, 3 * E), False)
-        a = CrossAttnFn.apply(q, kv, cu_t, cu_s, H, dh, mt, ms)
-        y = LinearFn.apply(a, ca.out_proj.weight, ca.out_proj.bias, x32, prec, wc, True)
+        a = CrossAttnFn.apply(q, kv, cu_t, cu_s, H, dh, mt, ms, _p_of(ca, tr))
+        y = _proj_residual(a, ca.out_proj.weight, ca.out_proj.bias, x32, _p_of(ly.dropout2, tr), prec, wc)
         x32 = LayerNormFn.apply(y, ly.norm2.weight, ly.norm2.bias, ly.norm2.eps)
         a1 = _lin(x32, ly.linear1.weight, ly.linear1.bias, prec, wc)
         h = GeluFn.apply(a1)
-        y = LinearFn.apply(h, ly.linear2.weight, ly.linear2.bias, x32, prec, wc, True)
+        if _p_of(ly.dropout, tr) > 0:
+            h = DropoutAddFn.apply(h, None, _p_of(ly.dropout, tr), _next_seed())
+        y = _proj_residual(h, ly.linear2.weight, ly.linear2.bias, x32, _p_of(ly.dropout3, tr), prec, wc)
         x32 = LayerNormFn.apply(y, ly.norm3.weight, ly.norm3.bias, ly.norm3.eps)
     nrm = dec.decoder_blocks.norm
     x32 = LayerNormFn.apply(x32, nrm.weight, nrm.bias, nrm.eps)

@@ -76,10 +76,12 @@ int acai_cast_f32_bf16(const float *x, void *y, int64_t n, void *stream);
  * nn.TransformerEncoderLayer M:30-34,186-190 and nn.TransformerDecoderLayer M:422-426).
  * q row i of sequence b is q + (cu_q[b]+i)*ldq + h*dh; same for k, v (cu_k) and out.
  * causal != 0 applies the triu(diagonal=1) mask of M:468.  dh <= 64.
- * lse (optional, [H][total_q] fp32): log2-domain log-sum-exp of the scaled scores, saved for acai_attn_varlen_bwd. */
+ * lse (optional, [H][total_q] fp32): log2-domain log-sum-exp of the scaled scores, saved for acai_attn_varlen_bwd.
+ * dropout_p > 0: attention-probability dropout (nn.MultiheadAttention(dropout=p) in train mode); the keep mask is a counter-based
+ * hash of (dropout_seed, head, query, key) that the backward regenerates. */
 int acai_attn_varlen_fwd(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, void *out, int ldo,
                          const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int causal,
-                         int dtype, float *lse, int total_q, void *stream);
+                         int dtype, float *lse, int total_q, float dropout_p, uint32_t dropout_seed, void *stream);
 
 /* Backward of acai_attn_varlen_fwd (autograd of the same SDPA; training loops pre_train.py:59, omr_teacher_force_train.py:118).
  * o / lse are the forward's outputs, dout the incoming gradient; dq/dk/dv take the layout of q/k/v (own row strides).
@@ -87,7 +89,7 @@ int acai_attn_varlen_fwd(const void *q, int ldq, const void *k, int ldk, const v
 int acai_attn_varlen_bwd(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, const void *o, int ldo,
                          const void *dout, int lddo, void *dq, int lddq, void *dk, int lddk, void *dv, int lddv, const float *lse,
                          float *delta, const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int max_k,
-                         int total_q, int causal, int dtype, void *stream);
+                         int total_q, int causal, int dtype, float dropout_p, uint32_t dropout_seed, void *stream);
 
 /* Backward of nn.LayerNorm: dx (fp32) from x, w, dy; dw/db (may be NULL) are ACCUMULATED with fp32 atomics (zero or seed them);
  * stats: workspace [rows][2]. */
@@ -100,6 +102,11 @@ int acai_gelu_bwd(const void *a, const void *dh, void *da, int64_t n, int dtype,
 int acai_colsum(const void *x, int ld, float *out, int rows, int cols, int dtype, void *stream);
 /* dst[idx[r],:] += src[r,:] (gradients of nn.Embedding M:460, pos_embedding slices M:50, MAE index_select M:114,229). */
 int acai_scatter_add_rows(const float *src, const int32_t *idx, float *dst, int rows, int dim, void *stream);
+/* nn.Dropout on a projection output followed by the residual add (torch TransformerEncoderLayer dropout1/dropout2, decoder dropout1-3,
+ * transition head M:658): out = residual + keep * x / (1 - p); residual may be NULL (plain dropout, and its own backward on dy).
+ * keep mask = counter-based hash of (seed, row, col). */
+int acai_dropout_add(const void *x, const float *residual, void *out, int rows, int cols, float p, uint32_t seed, int x_dtype, int out_dtype,
+                     void *stream);
 /* MAELoss (M:271-288) forward + backward on packed rows: *loss += sum_r mask_r * mean_d((pred - that)^2) * inv_count,
  * dpred (may be NULL) = d loss / d pred; that = (target - mean) / sqrt(var_unbiased + 1e-6). */
 int acai_mae_loss(const float *pred, const float *target, const unsigned char *mask, float inv_count, float *loss, float *dpred,
