@@ -12,6 +12,7 @@
 // delta[q] = sum_d dO[q,d] O[q,d] comes from attn_delta_kernel.  S and P are recomputed in both kernels (7 products instead
 // of 5) - the price of having no cross-workgroup reduction.  fp32: v_mfma_f32_32x32x2_f32, bf16: v_mfma_f32_32x32x16_bf16.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -97,6 +98,61 @@ __device__ __forceinline__ void mma_acc(f32x16 &acc, const unsigned char *tile, 
     }
 }
 
+// Streams 64-row tiles of two [rows][dh] operands (natural image) from global memory through registers into an LDS stage: the loads of
+// tile t+1 are issued before the MFMAs of tile t and written to the other stage after them (issue-early / write-late), so a tile
+// costs one barrier.  Per-thread global pointers advance by one tile per call; interior tiles load unguarded.
+template <typename T, int DHP, bool FAST>
+struct TileStager {
+    static constexpr int ES = sizeof(T), EPC = 16 / ES, RP = DHP * ES + 16, CPR = DHP / EPC, NCH = 64 * CPR / 256;
+    const T *pa[NCH], *pb[NCH], *A, *B;
+    int srow[NCH], soff[NCH], lda, ldb, dh;
+    bool dok[NCH];
+    uint4 ra[NCH], rb[NCH];
+    __device__ __forceinline__ void init(const T *A_, int lda_, const T *B_, int ldb_, int tid, int dh_, int first_tile) {
+        A = A_; B = B_; lda = lda_; ldb = ldb_; dh = dh_;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 256 * i, row = c / CPR, cc = c % CPR;
+            srow[i] = row;
+            soff[i] = row * RP + cc * 16;
+            dok[i] = cc * EPC < dh;
+            pa[i] = A + ((size_t)first_tile * 64 + row) * lda + cc * EPC;
+            pb[i] = B + ((size_t)first_tile * 64 + row) * ldb + cc * EPC;
+        }
+    }
+    // tiles must be requested in increasing order, one call per tile (the pointers advance)
+    __device__ __forceinline__ void load(int t, int rows) {
+        if constexpr (FAST) {
+            const bool full = (t + 1) * 64 <= rows;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                ra[i] = rb[i] = make_uint4(0, 0, 0, 0);
+                if (dok[i] && (full || t * 64 + srow[i] < rows)) {
+                    ra[i] = *reinterpret_cast<const uint4 *>(pa[i]);
+                    rb[i] = *reinterpret_cast<const uint4 *>(pb[i]);
+                }
+                pa[i] += (size_t)64 * lda;
+                pb[i] += (size_t)64 * ldb;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int cc = (threadIdx.x + 256 * i) % CPR;
+                ra[i] = ld16<T, false>(A, lda, t * 64 + srow[i], rows, cc * EPC, dh);
+                rb[i] = ld16<T, false>(B, ldb, t * 64 + srow[i], rows, cc * EPC, dh);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(unsigned char *stage) const {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            *reinterpret_cast<uint4 *>(stage + soff[i]) = ra[i];
+            *reinterpret_cast<uint4 *>(stage + 64 * RP + soff[i]) = rb[i];
+        }
+    }
+};
+
+
 // delta[h][q] = sum_d dO[q, h*dh + d] * O[q, h*dh + d]; one thread per (q, h), 16-byte loads when the head slice allows it
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const T *o, int ldo, const T *dout, int lddo, float *delta, int total_q, int H, int dh) {
@@ -121,13 +177,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T *o, int ldo, co
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int DHP, bool FAST>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
-    constexpr int ES = sizeof(T), EPC = 16 / ES;
+template <typename T, int DHP, bool FAST, bool DROP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dq_kernel(BwdArgs a) {
+    constexpr int ES = sizeof(T);
     constexpr int RP = DHP * ES + 16;   // pitch of the natural [row][d] tiles
-    constexpr int NS = DHP * ES / 32, NDB = DHP / 32, CPR = DHP / EPC, NCH = TT * CPR / 256;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *ldsK = smem, *ldsV = smem + TT * RP;
+    constexpr int NS = DHP * ES / 32, NDB = DHP / 32, STAGE = 2 * TT * RP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // two stages of {K tile, V tile}
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -160,16 +215,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
 
     int nkt = (lk + TT - 1) / TT;
     if (a.causal) nkt = min(nkt, (min(q0 + OB, lq) - 1) / TT + 1);
+    TileStager<T, DHP, FAST> stg;
+    stg.init(K, a.ldk, V, a.ldv, tid, dh, 0);
+    stg.load(0, lk);
+    stg.store(smem);
+    __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + 256 * i, row = c / CPR, cc = c % CPR;
-            const uint4 rk = ld16<T, FAST>(K, a.ldk, kt * TT + row, lk, cc * EPC, dh);
-            const uint4 rv = ld16<T, FAST>(V, a.ldv, kt * TT + row, lk, cc * EPC, dh);
-            *reinterpret_cast<uint4 *>(ldsK + row * RP + cc * 16) = rk;
-            *reinterpret_cast<uint4 *>(ldsV + row * RP + cc * 16) = rv;
-        }
-        __syncthreads();
+        const unsigned char *ldsK = smem + (kt & 1) * STAGE, *ldsV = ldsK + TT * RP;
+        if (kt + 1 < nkt) stg.load(kt + 1, lk);
         const int key_lim = a.causal ? min(lk, my_q + 1) : lk;
         const bool interior = (kt + 1) * TT <= (a.causal ? min(lk, q0 + wave * 32 + 1) : lk);  // every key valid for the whole wave
 #pragma unroll
@@ -179,7 +232,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
             for (int e = 0; e < 16; ++e) sacc[e] = dpacc[e] = 0.f;
             mma_rows<T, NS>(sacc, ldsK + kb * 32 * RP, RP, lr, lh, qf);     // S^T[key][q]
             mma_rows<T, NS>(dpacc, ldsV + kb * 32 * RP, RP, lr, lh, dof);   // dP^T[key][q]
-            if (a.drop_thr) {  // dP = mask/(1-p) o (dO V^T)
+            if constexpr (DROP) {  // dP = mask/(1-p) o (dO V^T)
                 const uint32_t rrow = (uint32_t)(h * a.total_q + q_start + my_q);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -201,6 +254,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
 #pragma unroll
             for (int d = 0; d < NDB; ++d) mma_acc<T>(dqacc[d], ldsK, RP, kb * 32, d * 32, lane, sacc);  // dQ^T += K^T dS^T
         }
+        if (kt + 1 < nkt) stg.store(smem + ((kt + 1) & 1) * STAGE);
         __syncthreads();
     }
     if (my_q < lq) {
@@ -216,14 +270,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int DHP, bool FAST>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
-    constexpr int ES = sizeof(T), EPC = 16 / ES;
+template <typename T, int DHP, bool FAST, bool DROP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DHP == 64) ? 1 : 2))) void attn_bwd_dkv_kernel(BwdArgs a) {
+    constexpr int ES = sizeof(T);
     constexpr int RP = DHP * ES + 16;
-    constexpr int NS = DHP * ES / 32, NDB = DHP / 32, CPR = DHP / EPC, NCH = TT * CPR / 256;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *ldsQ = smem, *ldsDO = smem + TT * RP;
-    float *ldsLse = reinterpret_cast<float *>(smem + 2 * TT * RP), *ldsDlt = ldsLse + TT;
+    constexpr int NS = DHP * ES / 32, NDB = DHP / 32, STAGE = 2 * TT * RP + 2 * TT * (int)sizeof(float);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // two stages of {Q tile, dO tile, lse[64], delta[64]}
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -254,22 +306,38 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
 
     const int nqt = (lq + TT - 1) / TT;
     const int qt0 = a.causal ? k0 / TT : 0;  // queries before this key block never attend to it
-    for (int qt = qt0; qt < nqt; ++qt) {
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + 256 * i, row = c / CPR, cc = c % CPR;
-            const uint4 rq = ld16<T, FAST>(Q, a.ldq, qt * TT + row, lq, cc * EPC, dh);
-            const uint4 rd = ld16<T, FAST>(DO, a.lddo, qt * TT + row, lq, cc * EPC, dh);
-            *reinterpret_cast<uint4 *>(ldsQ + row * RP + cc * 16) = rq;
-            *reinterpret_cast<uint4 *>(ldsDO + row * RP + cc * 16) = rd;
-        }
+    TileStager<T, DHP, FAST> stg;
+    stg.init(Q, a.ldq, DO, a.lddo, tid, dh, qt0);
+    const float *lse_row = a.lse + (size_t)h * a.total_q + q_start, *dlt_row = a.delta + (size_t)h * a.total_q + q_start;
+    float r_lse = 0.f, r_dlt = 0.f;
+    auto load_stats = [&](int qt) {   // threads 0..63: one query row's statistics each
         if (tid < TT) {
-            const int qq = qt * TT + tid;
-            const size_t sidx = (size_t)h * a.total_q + q_start + (qq < lq ? qq : 0);
-            ldsLse[tid] = a.lse[sidx];
-            ldsDlt[tid] = a.delta[sidx];
+            const int qq = qt * TT + tid, qi = qq < lq ? qq : 0;
+            r_lse = lse_row[qi];
+            r_dlt = dlt_row[qi];
         }
-        __syncthreads();
+    };
+    auto store_stats = [&](unsigned char *stage) {
+        if (tid < TT) {
+            reinterpret_cast<float *>(stage + 2 * TT * RP)[tid] = r_lse;
+            reinterpret_cast<float *>(stage + 2 * TT * RP)[TT + tid] = r_dlt;
+        }
+    };
+    if (qt0 < nqt) {
+        stg.load(qt0, lq);
+        load_stats(qt0);
+        stg.store(smem);
+        store_stats(smem);
+    }
+    __syncthreads();
+    for (int qt = qt0; qt < nqt; ++qt) {
+        const unsigned char *cur = smem + ((qt - qt0) & 1) * STAGE;
+        const unsigned char *ldsQ = cur, *ldsDO = cur + TT * RP;
+        const float *ldsLse = reinterpret_cast<const float *>(cur + 2 * TT * RP), *ldsDlt = ldsLse + TT;
+        if (qt + 1 < nqt) {
+            stg.load(qt + 1, lq);
+            load_stats(qt + 1);
+        }
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16 sacc, dpacc;
@@ -286,7 +354,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
             }
             // interior: every query of the tile exists, every key of the WAVE exists and (causal) lies at or before the tile's first query
             const bool interior = (qt + 1) * TT <= lq && k0 + wave * 32 + 32 <= lk && (!a.causal || k0 + wave * 32 + 31 <= qt * TT + qb * 32);
-            if (a.drop_thr) {  // keep mask of (query row, my key): dP is masked, and so is the P that multiplies dO for dV
+            if (DROP) {  // keep mask of (query row, my key): dP is masked, and so is the P that multiplies dO for dV
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int ql = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, qq = qt * TT + ql;
@@ -319,6 +387,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
                 mma_acc<T>(dkacc[d], ldsQ, RP, qb * 32, d * 32, lane, dpacc);   // dK^T += Q^T dS
             }
         }
+        if (qt + 1 < nqt) {
+            unsigned char *nxt = smem + ((qt + 1 - qt0) & 1) * STAGE;
+            stg.store(nxt);
+            store_stats(nxt);
+        }
         __syncthreads();
     }
     if (my_k < lk) {
@@ -342,15 +415,19 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, hipStream_t st) {
     const bool fast = (a.dh % EPC == 0) && (a.ldq % EPC == 0) && (a.ldk % EPC == 0) && (a.ldv % EPC == 0) && (a.lddo % EPC == 0) &&
                       aligned16(a.q) && aligned16(a.k) && aligned16(a.v) && aligned16(a.dout);
     constexpr int RP = DHP * ES + 16;
-    const size_t lds_dq = 2 * TT * RP, lds_dkv = 2 * TT * RP + 2 * TT * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_kernel<T, DHP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_kernel<T, DHP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_kernel<T, DHP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_kernel<T, DHP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr = true;
-    }
+    const size_t lds_dq = 2 * (2 * TT * RP), lds_dkv = 2 * (2 * TT * RP + 2 * TT * sizeof(float));   // two stages each
+    auto launch_pair = [&](auto drop, auto fst) {
+        constexpr bool D = decltype(drop)::value, F = decltype(fst)::value;
+        static bool attr = false;  // one flag per instantiation
+        if (!attr) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_kernel<T, DHP, F, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_kernel<T, DHP, F, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            attr = true;
+        }
+        dim3 gq(cdiv(max_q, OB), a.H, B), gk(cdiv(max_k, OB), a.H, B);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DHP, F, D>), gq, dim3(256), lds_dq, st, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DHP, F, D>), gk, dim3(256), lds_dkv, st, a);
+    };
     const bool vec = (a.dh % EPC == 0) && (a.ldo % EPC == 0) && (a.lddo % EPC == 0) && aligned16(a.o) && aligned16(a.dout);
     if (vec)
         hipLaunchKernelGGL((attn_delta_kernel<T, true>), dim3(cdiv(a.total_q * a.H, 256)), dim3(256), 0, st, (const T *)a.o, a.ldo, (const T *)a.dout,
@@ -359,13 +436,12 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, hipStream_t st) {
         hipLaunchKernelGGL((attn_delta_kernel<T, false>), dim3(cdiv(a.total_q * a.H, 256)), dim3(256), 0, st, (const T *)a.o, a.ldo, (const T *)a.dout,
                            a.lddo, const_cast<float *>(a.delta), a.total_q, a.H, a.dh);
     ACAI_LAUNCH_CHECK("attn_delta");
-    dim3 gq(cdiv(max_q, OB), a.H, B), gk(cdiv(max_k, OB), a.H, B);
-    if (fast) {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DHP, true>), gq, dim3(256), lds_dq, st, a);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DHP, true>), gk, dim3(256), lds_dkv, st, a);
+    if (a.drop_thr) {
+        if (fast) launch_pair(std::true_type{}, std::true_type{});
+        else launch_pair(std::true_type{}, std::false_type{});
     } else {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DHP, false>), gq, dim3(256), lds_dq, st, a);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DHP, false>), gk, dim3(256), lds_dkv, st, a);
+        if (fast) launch_pair(std::false_type{}, std::true_type{});
+        else launch_pair(std::false_type{}, std::false_type{});
     }
     ACAI_LAUNCH_CHECK("acai_attn_varlen_bwd");
     return 0;

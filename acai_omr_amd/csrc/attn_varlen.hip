@@ -13,7 +13,7 @@
 // fragment of k-step s when the A fragment takes keys 16s + 8(j>>2) + 4h + (j&3) (fp32: one register per
 // K=2 MFMA with A key (i&3)+8(i>>2)+4h).  bf16 -> v_mfma_f32_32x32x16_bf16, fp32 -> v_mfma_f32_32x32x2_f32.
 // Online softmax in fp32 with exp2 and a finite -1e30 floor; global loads of tile t+1 are issued before
-// the MFMAs of tile t (issue-early / write-late), one LDS stage.
+// the MFMAs of tile t (issue-early / write-late) into the other of two LDS stages: one barrier per tile.
 #include "common.h"
 
 namespace {
@@ -33,8 +33,8 @@ struct AttnArgs {
     int total_q;
 };
 
-template <typename T, int DHP, bool FAST>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+template <typename T, int DHP, bool FAST, bool DROP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_fwd_kernel(AttnArgs a) {
     constexpr int ES = sizeof(T);
     constexpr int EPC = 16 / ES;                 // elements per 16-byte chunk
     constexpr int KPITCH = DHP * ES + 16;        // bytes per K / V row in LDS (both tiles keep their natural [key][d] image)
@@ -42,8 +42,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     constexpr int NDB = DHP / 32;                // 32-wide d blocks of the output
     constexpr int CPR = DHP / EPC;               // 16-byte chunks per K/V row
     constexpr int NCH = KT * CPR / 256;          // chunks per thread per operand
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * KT * KPITCH];
-    unsigned char *ldsK = lds, *ldsV = lds + KT * KPITCH;
+    constexpr int STAGE = 2 * KT * KPITCH;       // one K tile + one V tile
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];   // two stages: tile t+1 is written while tile t is read
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
@@ -94,30 +94,57 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         nkt = min(nkt, last_q / KT + 1);
     }
 
+    // staging: thread -> NCH 16-byte chunks of the K and of the V tile; global pointers advance by one tile per iteration
     uint4 rk[NCH], rv[NCH];
-    auto load_tile = [&](int kt) {
+    const T *kp[NCH], *vp[NCH];
+    int srow[NCH], soff[NCH];
+    bool dok[NCH];
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + 256 * i, row = c / CPR, d0 = (c % CPR) * EPC;
-            rk[i] = load16(K, a.ldk, kt * KT + row, lk, d0);
-            rv[i] = load16(V, a.ldv, kt * KT + row, lk, d0);
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + 256 * i, row = c / CPR, cc = c % CPR;
+        srow[i] = row;
+        soff[i] = row * KPITCH + cc * 16;
+        dok[i] = cc * EPC < dh;
+        kp[i] = K + (size_t)row * a.ldk + cc * EPC;
+        vp[i] = V + (size_t)row * a.ldv + cc * EPC;
+    }
+    auto load_tile = [&](int kt) {
+        if constexpr (FAST) {
+            const bool full = (kt + 1) * KT <= lk;  // wave-uniform: interior tiles load unguarded
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const bool ok = dok[i] && (full || kt * KT + srow[i] < lk);
+                rk[i] = rv[i] = make_uint4(0, 0, 0, 0);
+                if (ok) {
+                    rk[i] = *reinterpret_cast<const uint4 *>(kp[i]);
+                    rv[i] = *reinterpret_cast<const uint4 *>(vp[i]);
+                }
+                kp[i] += (size_t)KT * a.ldk;
+                vp[i] += (size_t)KT * a.ldv;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = tid + 256 * i, d0 = (c % CPR) * EPC;
+                rk[i] = load16(K, a.ldk, kt * KT + srow[i], lk, d0);
+                rv[i] = load16(V, a.ldv, kt * KT + srow[i], lk, d0);
+            }
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](unsigned char *stage) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = tid + 256 * i, row = c / CPR, cc = c % CPR;
-            *reinterpret_cast<uint4 *>(ldsK + row * KPITCH + cc * 16) = rk[i];
-            *reinterpret_cast<uint4 *>(ldsV + row * KPITCH + cc * 16) = rv[i];
+            *reinterpret_cast<uint4 *>(stage + soff[i]) = rk[i];
+            *reinterpret_cast<uint4 *>(stage + KT * KPITCH + soff[i]) = rv[i];
         }
     };
 
     load_tile(0);
-    store_tile();
+    store_tile(lds);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
+        const unsigned char *ldsK = lds + (kt & 1) * STAGE, *ldsV = ldsK + KT * KPITCH;
         if (kt + 1 < nkt) load_tile(kt + 1);
-
         // ---- S^T = K . Q^T : two 32-key blocks ---------------------------------------------------------
         f32x16 sacc[2];
 #pragma unroll
@@ -143,7 +170,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         // wave) take a path without compares / selects: 1 max + 1 fma + 1 exp2 + 1 add per score.
         const int key_lim = a.causal ? min(lk, my_q + 1) : lk;  // keys < key_lim are attended
         const int wave_lim = a.causal ? min(lk, q0 + wave * 32 + 1) : lk;  // keys < wave_lim are valid for ALL lanes of the wave
-        float psum = 0.f, alpha;
+        // Lazy rescale: the running maximum is only raised (and O, l rescaled) when some lane's tile maximum exceeds it by more than 2^8;
+        // otherwise probabilities are taken against the stale maximum (p <= 256: exact in the final O / l ratio up to rounding).
+        float psum = 0.f, m_new;
+        auto raise_max = [&](float tmax) {
+            if (__builtin_amdgcn_ballot_w64(tmax > m_run + 8.0f) != 0) {  // wave-uniform
+                const float m2 = fmaxf(m_run, tmax);
+                const float alpha = fast_exp2(m_run - m2);
+                m_run = m2;
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+            }
+            return m_run;
+        };
         if ((kt + 1) * KT <= wave_lim) {
             float tmax = -1.0e30f;
 #pragma unroll
@@ -152,9 +194,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[kb][e]);
             tmax *= a.scale_log2e;
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            const float m_new = fmaxf(m_run, tmax);
-            alpha = fast_exp2(m_run - m_new);
-            m_run = m_new;
+            m_new = raise_max(tmax);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -175,9 +215,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                     tmax = fmaxf(tmax, sv);
                 }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            const float m_new = fmaxf(m_run, tmax);
-            alpha = fast_exp2(m_run - m_new);
-            m_run = m_new;
+            m_new = raise_max(tmax);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -188,8 +226,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                     psum += p;
                 }
         }
-        l_run = l_run * alpha + psum;
-        if (a.drop_thr) {  // the normaliser uses the undropped probabilities; only the P that multiplies V is masked and rescaled
+        l_run += psum;
+        if constexpr (DROP) {  // the normaliser uses the undropped probabilities; only the P that multiplies V is masked and rescaled
             const uint32_t rrow = (uint32_t)(h * a.total_q + q_start + my_q);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -199,11 +237,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                     sacc[kb][e] = drop_keep(a.drop_seed, rrow, key, a.drop_thr) ? sacc[kb][e] * a.drop_scale : 0.f;
                 }
         }
-#pragma unroll
-        for (int d = 0; d < NDB; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
-
         // ---- O^T += V^T . P^T --------------------------------------------------------------------------
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -244,11 +277,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 }
             }
         }
-        __syncthreads();
-        if (kt + 1 < nkt) {
-            store_tile();
-            __syncthreads();
-        }
+        if (kt + 1 < nkt) store_tile(lds + ((kt + 1) & 1) * STAGE);
+        __syncthreads();   // one barrier per tile: stage (kt+1)&1 was last read in iteration kt-1
     }
 
     // ---- normalise and store: lane owns query my_q, registers hold d = db*32 + (e&3) + 8*(e>>2) + 4*lh ------
@@ -290,10 +320,15 @@ int launch(const AttnArgs &a, int B, int max_q, hipStream_t st) {
     const bool fast = (a.dh % EPC == 0) && (a.ldq % EPC == 0) && (a.ldk % EPC == 0) && (a.ldv % EPC == 0) && (a.ldo % EPC == 0) &&
                       aligned16(a.q) && aligned16(a.k) && aligned16(a.v) && aligned16(a.out);
     dim3 grid(cdiv(max_q, QB), a.H, B);
-    if (fast)
-        hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, true>), grid, dim3(256), 0, st, a);
+    if (a.drop_thr) {  // train-mode attention dropout: its own instantiation, so the common kernel carries no hash code / registers
+        if (fast)
+            hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, true, true>), grid, dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, false, true>), grid, dim3(256), 0, st, a);
+    } else if (fast)
+        hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, true, false>), grid, dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, false>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, false, false>), grid, dim3(256), 0, st, a);
     ACAI_LAUNCH_CHECK("acai_attn_varlen_fwd");
     return 0;
 }

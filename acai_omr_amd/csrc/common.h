@@ -34,7 +34,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return __builtin_bit_cast(bf16_t, h);
 }
 __device__ __forceinline__ float round_bf16(float f) { return bf2f(f2bf(f)); }
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// two floats -> one dword of bf16 (RNE) with a single v_cvt_pk_bf16_f32 (separate scalar casts cost 2 cvt + shift + or)
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
 
 // 2^x as the bare v_exp_f32 (exp2f() adds a denormal-range fix-up of ~4 VALU ops per call; softmax arguments are <= 0 and
 // results below 2^-126 may flush to zero)
