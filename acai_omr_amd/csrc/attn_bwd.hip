@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     constexpr int NS = DHP * ES / 32, NDB = DHP / 32, STAGE = 2 * TT * RP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // two stages of {K tile, V tile}
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 31, lh = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
     const int q_start = a.cu_q[b], lq = a.cu_q[b + 1] - q_start;
     const int k_start = a.cu_k[b], lk = a.cu_k[b + 1] - k_start;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) 
     constexpr int NS = DHP * ES / 32, NDB = DHP / 32, STAGE = 2 * TT * RP + 2 * TT * (int)sizeof(float);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // two stages of {Q tile, dO tile, lse[64], delta[64]}
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 31, lh = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
     const int q_start = a.cu_q[b], lq = a.cu_q[b + 1] - q_start;
     const int k_start = a.cu_k[b], lk = a.cu_k[b + 1] - k_start;

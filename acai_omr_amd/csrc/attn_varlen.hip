@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     constexpr int STAGE = 2 * KT * KPITCH;       // one K tile + one V tile
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];   // two stages: tile t+1 is written while tile t is read
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform (SGPR): tile-class branches are scalar
     const int lr = lane & 31, lh = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
     const int q_start = a.cu_q[b], lq = a.cu_q[b + 1] - q_start;

@@ -57,6 +57,13 @@ __device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t row, uint3
 // keep probability 1 - p as a 32-bit threshold: keep iff hash >= thr
 __device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t row, uint32_t col, uint32_t thr) { return drop_hash(seed, row, col) >= thr; }
 
+// streamed-once 16-byte load (non-temporal: does not displace reusable lines in L2 / Infinity Cache)
+__device__ __forceinline__ uint4 ld_nt16(const void *p) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 // exact-erf GELU, as torch's F.gelu(approximate="none")
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

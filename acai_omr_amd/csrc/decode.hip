@@ -146,12 +146,6 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
 constexpr int SKM_MAXK = 4096;
 
 // 16-byte non-temporal load: decoder weights (and K/V) are read exactly once per decode step
-__device__ __forceinline__ uint4 ld_nt16(const void *p) {
-    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-    return make_uint4(v[0], v[1], v[2], v[3]);
-}
-
 template <int NV>
 __device__ __forceinline__ void skm_row_stats(const float4 (&v)[NV], int K, int lane, float eps, float &mean, float &rstd) {
     float s = 0.f;

@@ -4,6 +4,7 @@
 //   (gradients of nn.Embedding, pos_embedding slices, MAE shuffle), MAELoss (models.py:271-288) and OMRCELoss
 //   (models.py:784-796) forward + backward in one pass each.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -65,6 +66,83 @@ __global__ __launch_bounds__(256) void ln_bwd_param_kernel(const float *__restri
     }
 }
 
+// Fused form for dim = NV * 256 (the path's 512 / 768 / 1024): one pass over x and dy.  A wave owns a row in registers (lane = 4 consecutive
+// columns per 256-column slab: 1 KiB per wave instruction), writes dx (fp32 and, optionally, the bf16 copy the next GEMM reads) and keeps
+// per-lane partial dw / db over all rows of its chunk; the four waves' partials meet in LDS and leave as one atomic per column and workgroup.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ dy, float eps,
+                                                           float *__restrict__ dx, bf16_t *__restrict__ dx_bf16, float *dw, float *db, int rows,
+                                                           int rows_per_block) {
+    constexpr int DIM = NV * 256;
+    __shared__ float red[4][DIM];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    f32x4 wv[NV], aw[NV], ab[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        wv[j] = *reinterpret_cast<const f32x4 *>(w + j * 256 + lane * 4);
+        aw[j] = ab[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float inv_dim = 1.0f / (float)DIM;
+    for (int r = r0 + wave; r < r1; r += 4) {
+        f32x4 xv[NV], gv[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            xv[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(x + (size_t)r * DIM + j * 256 + lane * 4));
+            gv[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(dy + (size_t)r * DIM + j * 256 + lane * 4));
+            s += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
+        }
+        const float mean = wave_sum(s) * inv_dim;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xv[j][e] -= mean;
+                q += xv[j][e] * xv[j][e];
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_dim + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = xv[j][e] * rstd, d = gv[j][e], g = d * wv[j][e];
+                xv[j][e] = xh;
+                aw[j][e] += d * xh;
+                ab[j][e] += d;
+                gv[j][e] = g;
+                sg += g;
+                sgx += g * xh;
+            }
+        sg = wave_sum(sg) * inv_dim;
+        sgx = wave_sum(sgx) * inv_dim;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = rstd * (gv[j][e] - sg - xv[j][e] * sgx);
+            *reinterpret_cast<f32x4 *>(dx + (size_t)r * DIM + j * 256 + lane * 4) = o;
+            if (dx_bf16) {
+                uint2 pk;
+                pk.x = pack_bf16(o[0], o[1]);
+                pk.y = pack_bf16(o[2], o[3]);
+                *reinterpret_cast<uint2 *>(dx_bf16 + (size_t)r * DIM + j * 256 + lane * 4) = pk;
+            }
+        }
+    }
+    if (!dw) return;  // uniform
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) *reinterpret_cast<f32x4 *>(&red[wave][j * 256 + lane * 4]) = pass ? ab[j] : aw[j];
+        __syncthreads();
+        for (int c = threadIdx.x; c < DIM; c += 256) atomicAdd((pass ? db : dw) + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+        __syncthreads();
+    }
+}
+
 // ---- GELU ----------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T *__restrict__ a, T *h, long n) {
@@ -92,6 +170,45 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ x, in
     s[wave][lane] = acc;
     __syncthreads();
     if (wave == 0 && c < cols) atomicAdd(out + c, s[0][lane] + s[1][lane] + s[2][lane] + s[3][lane]);
+}
+
+// 16-byte form: a lane owns EPC consecutive columns, a wave 64*EPC columns of one row (1 KiB per wave instruction), the four waves interleave
+// rows, four rows in flight per lane.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T *__restrict__ x, int ld, float *out, int rows, int cols, int rows_per_block) {
+    constexpr int EPC = 16 / sizeof(T);
+    __shared__ float s[4][64 * EPC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 64 + lane) * EPC;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    if (c0 < cols) {
+        const T *p = x + c0;
+        auto add = [&](const uint4 &v) {
+            union { uint4 u; T e[EPC]; } t;
+            t.u = v;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] += DT<T>::ld(&t.e[e]);
+        };
+        int r = r0 + wave;
+        for (; r + 12 < r1; r += 16) {
+            const uint4 v0 = ld_nt16(p + (size_t)r * ld);
+            const uint4 v1 = ld_nt16(p + (size_t)(r + 4) * ld);
+            const uint4 v2 = ld_nt16(p + (size_t)(r + 8) * ld);
+            const uint4 v3 = ld_nt16(p + (size_t)(r + 12) * ld);
+            add(v0); add(v1); add(v2); add(v3);
+        }
+        for (; r < r1; r += 4) add(*reinterpret_cast<const uint4 *>(p + (size_t)r * ld));
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s[wave][lane * EPC + e] = acc[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 64 * EPC; c += 256) {
+        const int col = blockIdx.x * 64 * EPC + c;
+        if (col < cols) atomicAdd(out + col, (s[0][c] + s[1][c]) + (s[2][c] + s[3][c]));
+    }
 }
 
 // ---- dst[idx[r], :] += src[r, :] -------------------------------------------------------------------------------------------
@@ -180,11 +297,26 @@ static inline int grid1d(long n) {
 
 }  // namespace
 
-extern "C" int acai_layernorm_bwd(const float *x, const float *w, const float *dy, float eps, float *dx, float *dw, float *db, float *stats,
-                                  int rows, int dim, void *stream) {
+extern "C" int acai_layernorm_bwd(const float *x, const float *w, const float *dy, float eps, float *dx, void *dx_bf16, float *dw, float *db,
+                                  float *stats, int rows, int dim, void *stream) {
     ACAI_CHECK_ARG(x && w && dy && dx && stats && rows >= 0 && dim > 0, "acai_layernorm_bwd: bad arguments");
+    ACAI_CHECK_ARG((dw == nullptr) == (db == nullptr), "acai_layernorm_bwd: dw and db come together");
     if (rows == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (dim % 256 == 0 && dim <= 1024 && aligned16(x) && aligned16(dy) && aligned16(w) && aligned16(dx) && (!dx_bf16 || aligned16(dx_bf16))) {
+        const int rpb = std::max(4, cdiv(cdiv(rows, 2048), 4) * 4);   // ~2048 workgroups, whole groups of 4 rows (one per wave)
+        const dim3 grid(cdiv(rows, rpb));
+        bf16_t *xb = (bf16_t *)dx_bf16;
+        switch (dim / 256) {
+            case 1: hipLaunchKernelGGL(ln_bwd_fused_kernel<1>, grid, dim3(256), 0, st, x, w, dy, eps, dx, xb, dw, db, rows, rpb); break;
+            case 2: hipLaunchKernelGGL(ln_bwd_fused_kernel<2>, grid, dim3(256), 0, st, x, w, dy, eps, dx, xb, dw, db, rows, rpb); break;
+            case 3: hipLaunchKernelGGL(ln_bwd_fused_kernel<3>, grid, dim3(256), 0, st, x, w, dy, eps, dx, xb, dw, db, rows, rpb); break;
+            default: hipLaunchKernelGGL(ln_bwd_fused_kernel<4>, grid, dim3(256), 0, st, x, w, dy, eps, dx, xb, dw, db, rows, rpb); break;
+        }
+        ACAI_LAUNCH_CHECK("acai_layernorm_bwd");
+        return 0;
+    }
+    ACAI_CHECK_ARG(!dx_bf16, "acai_layernorm_bwd: the bf16 copy of dx needs dim %% 256 == 0, dim <= 1024 and 16-byte aligned operands");
     hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, w, dy, eps, dx, stats, rows, dim);
     if (dw && db) {
         const int rpb = 2048;
@@ -217,6 +349,16 @@ extern "C" int acai_gelu_bwd(const void *a, const void *dh, void *da, int64_t n,
 extern "C" int acai_colsum(const void *x, int ld, float *out, int rows, int cols, int dtype, void *stream) {
     ACAI_CHECK_ARG(x && out && rows >= 0 && cols > 0 && ld >= cols, "acai_colsum: bad arguments");
     if (rows == 0) return 0;
+    const int es = dtype == ACAI_BF16 ? 2 : 4, epc = 16 / es;
+    if (cols % epc == 0 && ld % epc == 0 && aligned16(x)) {
+        const int gx = cdiv(cols, 64 * epc);
+        const int rpb = std::max(64, cdiv(cdiv(rows, std::max(1, 2048 / gx)), 16) * 16);
+        dim3 grid(gx, cdiv(rows, rpb));
+        if (dtype == ACAI_BF16) hipLaunchKernelGGL(colsum_vec_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t *)x, ld, out, rows, cols, rpb);
+        else hipLaunchKernelGGL(colsum_vec_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)x, ld, out, rows, cols, rpb);
+        ACAI_LAUNCH_CHECK("acai_colsum");
+        return 0;
+    }
     const int rpb = 2048;
     dim3 grid(cdiv(cols, 64), cdiv(rows, rpb));
     if (dtype == ACAI_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t *)x, ld, out, rows, cols, rpb);

@@ -229,17 +229,19 @@ def dropout_add(x, residual, p, seed, out_dtype=None):
     return out
 
 
-def layernorm_bwd(x, w, dy, eps, want_param_grads=True):
+def layernorm_bwd(x, w, dy, eps, want_param_grads=True, want_bf16=False):
+    """Returns (dx, dw, db) or, with want_bf16 (dim % 256 == 0, dim <= 1024), (dx, dw, db, dx_bf16)."""
     _chk(x, "x", torch.float32), _chk(dy, "dy", torch.float32)
     assert x.is_contiguous() and dy.is_contiguous() and x.shape == dy.shape
     rows, dim = x.shape
     dx = torch.empty_like(x)
+    dxb = torch.empty(rows, dim, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
     stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
     dw = torch.zeros(dim, dtype=torch.float32, device=x.device) if want_param_grads else None
     db = torch.zeros(dim, dtype=torch.float32, device=x.device) if want_param_grads else None
-    _lib.check(_lib.lib().acai_layernorm_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), float(eps), dx.data_ptr(), _p(dw), _p(db), stats.data_ptr(),
-                                             rows, dim, _st()), "acai_layernorm_bwd")
-    return dx, dw, db
+    _lib.check(_lib.lib().acai_layernorm_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), float(eps), dx.data_ptr(), _p(dxb), _p(dw), _p(db),
+                                             stats.data_ptr(), rows, dim, _st()), "acai_layernorm_bwd")
+    return (dx, dw, db, dxb) if want_bf16 else (dx, dw, db)
 
 
 def gelu_fwd(a):

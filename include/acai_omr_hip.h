@@ -91,10 +91,11 @@ int acai_attn_varlen_bwd(const void *q, int ldq, const void *k, int ldk, const v
                          float *delta, const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int max_k,
                          int total_q, int causal, int dtype, float dropout_p, uint32_t dropout_seed, void *stream);
 
-/* Backward of nn.LayerNorm: dx (fp32) from x, w, dy; dw/db (may be NULL) are ACCUMULATED with fp32 atomics (zero or seed them);
- * stats: workspace [rows][2]. */
-int acai_layernorm_bwd(const float *x, const float *w, const float *dy, float eps, float *dx, float *dw, float *db, float *stats,
-                       int rows, int dim, void *stream);
+/* Backward of nn.LayerNorm: dx (fp32) from x, w, dy; dw/db (both or neither NULL) are ACCUMULATED with fp32 atomics (zero or seed
+ * them); dx_bf16 (may be NULL; needs dim % 256 == 0, dim <= 1024): bf16 copy of dx for the GEMM that consumes it; stats: workspace
+ * [rows][2]. */
+int acai_layernorm_bwd(const float *x, const float *w, const float *dy, float eps, float *dx, void *dx_bf16, float *dw, float *db,
+                       float *stats, int rows, int dim, void *stream);
 /* exact-erf GELU as a stand-alone pass (training keeps the pre-activation) and its derivative: da = dh * gelu'(a). */
 int acai_gelu_fwd(const void *a, void *h, int64_t n, int dtype, void *stream);
 int acai_gelu_bwd(const void *a, const void *dh, void *da, int64_t n, int dtype, void *stream);

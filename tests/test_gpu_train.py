@@ -256,3 +256,26 @@ def test_training_with_dropout_runs_and_is_seeded(dev):
     with torch.no_grad():
         pred, tgt = m(batch)
     assert abs(float(OMRCELoss(1)(pred, tgt)) - float(fx["loss"])) < 1e-4   # ... and eval mode is the reference's deterministic value
+
+
+@pytest.mark.parametrize("dim", [256, 512, 768, 1024, 96])
+def test_layernorm_bwd_fused_and_colsum_vec(dev, dim):
+    """The one-pass LayerNorm backward (dim % 256 == 0) and the generic two-kernel form against torch autograd; bf16 side copy; 16-byte colsum."""
+    from acai_omr_amd import ops
+    g = torch.Generator().manual_seed(dim)
+    rows = 1037
+    x = (torch.randn(rows, dim, generator=g) * 2 + 0.5).to(dev)
+    w = torch.randn(dim, generator=g).to(dev)
+    b = torch.randn(dim, generator=g).to(dev)
+    dy = torch.randn(rows, dim, generator=g).to(dev)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    torch.nn.functional.layer_norm(xr, (dim,), wr, br, 1e-5).backward(dy)
+    if dim % 256 == 0:
+        dx, dw, db, dxb = ops.layernorm_bwd(x, w, dy, 1e-5, want_bf16=True)
+        assert torch.equal(dxb, dx.to(torch.bfloat16))
+    else:
+        dx, dw, db = ops.layernorm_bwd(x, w, dy, 1e-5)
+    assert torch.allclose(dx, xr.grad, atol=2e-5, rtol=1e-4)
+    assert torch.allclose(dw, wr.grad, atol=2e-3, rtol=1e-4) and torch.allclose(db, br.grad, atol=2e-3, rtol=1e-4)
+    for t in (dy, dy.to(torch.bfloat16), dy[:, : dim - 8]):
+        assert torch.allclose(ops.colsum(t), t.float().sum(0), atol=2e-3, rtol=1e-3)
