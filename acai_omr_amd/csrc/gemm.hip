@@ -267,22 +267,31 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 // ---- NT main loop with direct-to-LDS staging (global_load_lds, 16 B per lane) ------------------------------------------------
 // For row-major operands with K % BK == 0: no staging VGPRs, two LDS stages (64 KB), tile t+1 in flight while tile t feeds the MFMAs,
 // one barrier per K-step.  An LDS-DMA wave instruction writes 1 KiB linearly (lane l -> base + 16 l = row l/8, slot l%8 of an unpadded
-// 128-byte row), so the bank-conflict fix is an XOR swizzle applied on BOTH sides: lane l fetches the global chunk (l%8) ^ (row%8) and
-// the fragment read of logical chunk c goes to slot c ^ (row%8).  Rows beyond M / N are clamped (their outputs are never stored).
-template <typename T, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs g) {
+// 128-byte row), so the bank-conflict fix is an XOR swizzle applied on BOTH sides: lane l fetches the global chunk (l%8) ^ ((row/2)%8) and
+// the fragment read of logical chunk c goes to slot c ^ ((row/2)%8).  Rows beyond M / N are clamped (their outputs are never stored).
+// WM = waves along M: 2 -> 128x128 tile, 4 waves (two workgroups per CU); 4 -> 256x128 tile, 8 waves (one workgroup per CU).  A CU takes in
+// only ~55 GB/s through the LDS-DMA path, which caps the 128x128 tile (64 flop per staged byte) near 0.9 PF; the 256-row tile stages
+// 25 % fewer bytes per flop and is used whenever it still yields >= 2 tiles per CU.
+template <typename T, int EPI, int WM>
+__global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_glds_kernel(GemmArgs g) {
     constexpr int BK = ROWB / sizeof(T);
-    constexpr int STAGE = (BM + BN) * ROWB;  // 32 KB
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+    constexpr int BMT = WM * 64, NW = WM * 2;          // tile rows, waves
+    constexpr int GA = BMT / 8 / NW, GW = BN / 8 / NW;  // 8-row groups (1 KiB LDS-DMA instructions) per wave and K-step: A, W
+    constexpr int STAGE = (BMT + BN) * ROWB;           // 32 / 48 KB
+    // Two DISTINCT LDS objects, addressed statically (the K loop is unrolled by two): the compiler's wait-count pass can then prove that
+    // the fragment reads of one stage do not alias the LDS-DMA in flight into the other.  With one array and a run-time stage index it
+    // put `s_waitcnt vmcnt(0)` in front of the first ds_read of every K-step, i.e. it drained tile t+1 before computing tile t.
+    __shared__ __attribute__((aligned(16))) unsigned char lds0[STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char lds1[STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
-    const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BM - 1) / BM, nwg = nbn * nbm;
+    const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BMT - 1) / BMT, nwg = nbn * nbm;
     int pid = blockIdx.x;
     {
         const int q = nwg / 8, r = nwg % 8, xcd = pid % 8, idx = pid / 8;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int bm0 = (pid / nbn) * BM, bn0 = (pid % nbn) * BN;
+    const int bm0 = (pid / nbn) * BMT, bn0 = (pid % nbn) * BN;
     const T *A = reinterpret_cast<const T *>(g.A);
     const T *W = reinterpret_cast<const T *>(g.W);
     f32x16 acc[2][2];
@@ -293,54 +302,79 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // this lane's source chunk inside an 8-row group: row l/8, swizzled slot
-    const int grow = lane >> 3, gslot = (lane & 7) ^ (grow & 7);
-    const T *srcA[4], *srcW[4];
+    // this lane's source chunk inside an 8-row group: row l/8; the 16-byte slot is XORed with bits 1..3 of the tile row (see SWZ below)
+    const int grow = lane >> 3;
+    const T *srcA[GA], *srcW[GW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + grow;
+    for (int i = 0; i < GA; ++i) {
+        const int row = (wave * GA + i) * 8 + grow;
+        const int gslot = (lane & 7) ^ ((row >> 1) & 7);
         srcA[i] = A + (size_t)min(bm0 + row, g.M - 1) * g.lda + gslot * (16 / sizeof(T));
+    }
+#pragma unroll
+    for (int i = 0; i < GW; ++i) {
+        const int row = (wave * GW + i) * 8 + grow;
+        const int gslot = (lane & 7) ^ ((row >> 1) & 7);
         srcW[i] = W + (size_t)min(bn0 + row, g.N - 1) * g.ldw + gslot * (16 / sizeof(T));
     }
     typedef __attribute__((address_space(3))) void *lds_ptr;
     typedef const __attribute__((address_space(1))) void *glb_ptr;
-    auto issue = [&](int kt, int stage) {
-        unsigned char *base = lds + stage * STAGE;
+    auto issue = [&](int kt, unsigned char *base) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_ptr)(srcA[i] + (size_t)kt * BK), (lds_ptr)(base + (wave * 4 + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr)(srcW[i] + (size_t)kt * BK), (lds_ptr)(base + BM * ROWB + (wave * 4 + i) * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < GA; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr)(srcA[i] + (size_t)kt * BK), (lds_ptr)(base + (wave * GA + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < GW; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr)(srcW[i] + (size_t)kt * BK), (lds_ptr)(base + BMT * ROWB + (wave * GW + i) * 1024), 16, 0, 0);
     };
-    const int nkt = g.K / BK;
-    issue(0, 0);
-    __syncthreads();  // with an LDS-DMA in flight this is s_waitcnt vmcnt(0) + s_barrier
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
-        const unsigned char *sa = lds + (kt & 1) * STAGE, *sb = sa + BM * ROWB;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            uint4 fa[2], fb[2];
+    // Fragment read of logical 16-byte chunk c of tile row r goes to slot c ^ ((r >> 1) & 7).  A 256-byte bank row holds two tile rows, and a
+    // ds_read_b128 is served 16 lanes (= 16 consecutive tile rows, one k-half) per cycle: bit 0 of r picks the half of the bank row, bits 1..3 the
+    // slot inside it, so the 16 lanes hit 16 different 16-byte bank groups (slot ^ (r & 7) paired rows r and r + 8: 2-way conflicts).
+    // Fragments are double-buffered: the reads of k-slice s+1 are issued before the MFMAs of slice s.
+    auto compute = [&](const unsigned char *sa) {
+        const unsigned char *sb = sa + BMT * ROWB;
+        uint4 fa[2][2], fb[2][2];
+        auto frags = [&](int s, uint4 (&xa)[2], uint4 (&xb)[2]) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int ra = wm * 64 + i * 32 + lr, rb = wn * 64 + i * 32 + lr;
-                fa[i] = *reinterpret_cast<const uint4 *>(sa + ra * ROWB + (((s * 2 + lh) ^ (ra & 7)) << 4));
-                fb[i] = *reinterpret_cast<const uint4 *>(sb + rb * ROWB + (((s * 2 + lh) ^ (rb & 7)) << 4));
+                xa[i] = *reinterpret_cast<const uint4 *>(sa + ra * ROWB + (((s * 2 + lh) ^ ((ra >> 1) & 7)) << 4));
+                xb[i] = *reinterpret_cast<const uint4 *>(sb + rb * ROWB + (((s * 2 + lh) ^ ((rb >> 1) & 7)) << 4));
             }
+        };
+        frags(0, fa[0], fb[0]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s + 1 < 4) frags(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if constexpr (sizeof(T) == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][i]), __builtin_bit_cast(bf16x8, fb[s & 1][j]), acc[i][j], 0, 0, 0);
                     } else {
-                        const f32x4 a4 = __builtin_bit_cast(f32x4, fa[i]), b4 = __builtin_bit_cast(f32x4, fb[j]);
+                        const f32x4 a4 = __builtin_bit_cast(f32x4, fa[s & 1][i]), b4 = __builtin_bit_cast(f32x4, fb[s & 1][j]);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[i][j], 0, 0, 0);
                     }
                 }
         }
-        __syncthreads();  // tile kt+1 has landed (vmcnt(0)) and every wave is done reading stage kt&1
+    };
+    const int nkt = g.K / BK;
+    issue(0, lds0);
+    __syncthreads();  // with an LDS-DMA in flight this is s_waitcnt vmcnt(0) + s_barrier
+    int kt = 0;
+    for (; kt + 2 <= nkt; kt += 2) {
+        issue(kt + 1, lds1);
+        compute(lds0);
+        __syncthreads();  // tile kt+1 has landed (vmcnt(0)) and every wave is done reading stage 0
+        if (kt + 2 < nkt) issue(kt + 2, lds0);
+        compute(lds1);
+        __syncthreads();
+    }
+    if (kt < nkt) {  // odd tile count: the last tile sits in stage 0
+        compute(lds0);
+        __syncthreads();
     }
     // ---- epilogue ---------------------------------------------------------------------------------------------------------
     // The MFMA C/D layout gives a lane one column and 16 scattered rows: storing from it means 2- or 4-byte stores in 64/128-byte
@@ -353,7 +387,199 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs g) {
         gemm_epilogue<EPI, false>(g, acc, bm0, bn0, wm, wn, lr, lh);
         return;
     }
-    float *stg = reinterpret_cast<float *>(lds + wave * 16384);
+    // every wave is past the last barrier: both stages are free; a wave stages 32 rows x 68 floats = 8.5 KB
+    float *stg = reinterpret_cast<float *>((wave < WM ? lds0 : lds1) + (wave % WM) * (STAGE / WM));
+    const bool do_gelu = g.flags & ACAI_GEMM_GELU, do_round = g.flags & ACAI_GEMM_ROUND_BF16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = bn0 + wn * 64 + j * 32 + lr;
+            const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[i][j][e] + bv;
+                if (do_round) v = round_bf16(v);
+                if (do_gelu) {
+                    v = gelu_erf(v);
+                    if (do_round) v = round_bf16(v);
+                }
+                stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * EP + j * 32 + lr] = v;
+            }
+        }
+        // same wave wrote and now reads: LDS operations of a wave complete in order
+        const int row_base = bm0 + wm * 64 + i * 32, col_base = bn0 + wn * 64;
+        if (g.out_dtype == ACAI_BF16) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = it * 64 + lane, r = idx >> 3, c8 = (idx & 7) * 8;
+                const int row = row_base + r;
+                if (row < g.M && c8 < n_valid) {
+                    f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c8), v1 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c8 + 4);
+                    if (g.residual) {
+                        const float *rp = g.residual + (size_t)row * g.ldr + col_base + c8;
+                        const f32x4 r0 = *reinterpret_cast<const f32x4 *>(rp), r1 = *reinterpret_cast<const f32x4 *>(rp + 4);
+                        v0 += r0;
+                        v1 += r1;
+                    }
+                    uint4 o;
+                    o.x = pack_bf16(v0[0], v0[1]); o.y = pack_bf16(v0[2], v0[3]); o.z = pack_bf16(v1[0], v1[1]); o.w = pack_bf16(v1[2], v1[3]);
+                    *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(g.C) + (size_t)row * ldc_e + col_base + c8) = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = it * 64 + lane, r = idx >> 4, c4 = (idx & 15) * 4;
+                const int row = row_base + r;
+                if (row < g.M && c4 < n_valid) {
+                    f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c4);
+                    if (g.residual) v0 += *reinterpret_cast<const f32x4 *>(g.residual + (size_t)row * g.ldr + col_base + c4);
+                    *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)row * ldc_e + col_base + c4) = v0;
+                }
+            }
+        }
+    }
+}
+
+// ---- 256x128 tile, 8 waves, THREE LDS stages (144 KB): two K-tiles in flight ------------------------------------------------------------
+// The two-stage kernels are latency-bound, not MFMA-bound (PMC: MFMA busy 36 %, a third of the wave cycles in s_waitcnt, L2 hit rate 64 %):
+// with one tile in flight per workgroup a CU has 64 KB outstanding, and 64 KB x 256 CUs / ~1.2 us of loaded L2/fabric latency is exactly the
+// ~13.7 TB/s staging rate observed at 0.88 PF.  Throughput = (bytes in flight) x (flop per staged byte) / latency, so this variant keeps
+// 2 x 48 KB in flight per CU on a tile with 1.33x the flop per byte.  One barrier per K-step:
+//     s_waitcnt vmcnt(6)   this wave's six LDS-DMA instructions of tile t have landed (those of t+1 may still fly)
+//     s_barrier            everybody's have; and everybody is done reading tile t-1, whose stage is reused next
+//     issue tile t+2 -> stage (t+2) % 3;  MFMAs of tile t from stage t % 3
+// (wait and barrier are one asm block: the fence inside __syncthreads() would drain vmcnt to 0).
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_glds3_kernel(GemmArgs g) {
+    constexpr int WM = 4;
+    constexpr int BK = ROWB / sizeof(T);
+    constexpr int BMT = WM * 64, NW = WM * 2;          // tile rows, waves
+    constexpr int GA = BMT / 8 / NW, GW = BN / 8 / NW;  // 8-row groups (1 KiB LDS-DMA instructions) per wave and K-step: A, W
+    constexpr int STAGE = (BMT + BN) * ROWB;           // 32 / 48 KB
+    // DISTINCT LDS objects, addressed statically (the K loop is unrolled by the stage count): the compiler's wait-count pass can then prove that
+    // the fragment reads of one stage do not alias the LDS-DMA in flight into the other.  With one array and a run-time stage index it
+    // put `s_waitcnt vmcnt(0)` in front of the first ds_read of every K-step, i.e. it drained tile t+1 before computing tile t.
+    __shared__ __attribute__((aligned(16))) unsigned char lds0[STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char lds1[STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char lds2[STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+    const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BMT - 1) / BMT, nwg = nbn * nbm;
+    int pid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = pid % 8, idx = pid / 8;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm0 = (pid / nbn) * BMT, bn0 = (pid % nbn) * BN;
+    const T *A = reinterpret_cast<const T *>(g.A);
+    const T *W = reinterpret_cast<const T *>(g.W);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // this lane's source chunk inside an 8-row group: row l/8; the 16-byte slot is XORed with bits 1..3 of the tile row (see SWZ below)
+    const int grow = lane >> 3;
+    const T *srcA[GA], *srcW[GW];
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+        const int row = (wave * GA + i) * 8 + grow;
+        const int gslot = (lane & 7) ^ ((row >> 1) & 7);
+        srcA[i] = A + (size_t)min(bm0 + row, g.M - 1) * g.lda + gslot * (16 / sizeof(T));
+    }
+#pragma unroll
+    for (int i = 0; i < GW; ++i) {
+        const int row = (wave * GW + i) * 8 + grow;
+        const int gslot = (lane & 7) ^ ((row >> 1) & 7);
+        srcW[i] = W + (size_t)min(bn0 + row, g.N - 1) * g.ldw + gslot * (16 / sizeof(T));
+    }
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    typedef const __attribute__((address_space(1))) void *glb_ptr;
+    // The LDS-DMA instructions are issued from inline asm: the compiler's wait-count pass tracks only a few LDS-DMA writers and, past that,
+    // guards every LDS read with s_waitcnt vmcnt(0) - which would drain the two tiles in flight.  Hidden from it, the only vmcnt waits in the
+    // loop are the counted ones below (no other vector-memory instruction is issued between the prologue and the epilogue).
+    auto issue = [&](int kt, unsigned char *base) {
+        const uint32_t lbase = (uint32_t)(uintptr_t)(lds_ptr)base;
+#pragma unroll
+        for (int i = 0; i < GA; ++i) {
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lbase + (wave * GA + i) * 1024);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(srcA[i] + (size_t)kt * BK) : "memory", "m0");
+        }
+#pragma unroll
+        for (int i = 0; i < GW; ++i) {
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lbase + BMT * ROWB + (wave * GW + i) * 1024);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(srcW[i] + (size_t)kt * BK) : "memory", "m0");
+        }
+    };
+    // Fragment read of logical 16-byte chunk c of tile row r goes to slot c ^ ((r >> 1) & 7).  A 256-byte bank row holds two tile rows, and a
+    // ds_read_b128 is served 16 lanes (= 16 consecutive tile rows, one k-half) per cycle: bit 0 of r picks the half of the bank row, bits 1..3 the
+    // slot inside it, so the 16 lanes hit 16 different 16-byte bank groups (slot ^ (r & 7) paired rows r and r + 8: 2-way conflicts).
+    // Fragments are double-buffered: the reads of k-slice s+1 are issued before the MFMAs of slice s.
+    auto compute = [&](const unsigned char *sa) {
+        const unsigned char *sb = sa + BMT * ROWB;
+        uint4 fa[2][2], fb[2][2];
+        auto frags = [&](int s, uint4 (&xa)[2], uint4 (&xb)[2]) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ra = wm * 64 + i * 32 + lr, rb = wn * 64 + i * 32 + lr;
+                xa[i] = *reinterpret_cast<const uint4 *>(sa + ra * ROWB + (((s * 2 + lh) ^ ((ra >> 1) & 7)) << 4));
+                xb[i] = *reinterpret_cast<const uint4 *>(sb + rb * ROWB + (((s * 2 + lh) ^ ((rb >> 1) & 7)) << 4));
+            }
+        };
+        frags(0, fa[0], fb[0]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s + 1 < 4) frags(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (sizeof(T) == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][i]), __builtin_bit_cast(bf16x8, fb[s & 1][j]), acc[i][j], 0, 0, 0);
+                    } else {
+                        const f32x4 a4 = __builtin_bit_cast(f32x4, fa[s & 1][i]), b4 = __builtin_bit_cast(f32x4, fb[s & 1][j]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+    };
+    static_assert(GA + GW == 6, "the counted wait below assumes six LDS-DMA instructions per wave and tile");
+    const int nkt = g.K / BK;
+    issue(0, lds0);
+    if (nkt > 1) issue(1, lds1);
+    auto step = [&](int kt, const unsigned char *cur, unsigned char *nxt2) {
+        if (kt + 1 < nkt)
+            asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + 2 < nkt) issue(kt + 2, nxt2);
+        compute(cur);
+    };
+    for (int kt = 0; kt < nkt; kt += 3) {
+        step(kt, lds0, lds2);
+        if (kt + 1 < nkt) step(kt + 1, lds1, lds0);
+        if (kt + 2 < nkt) step(kt + 2, lds2, lds1);
+    }
+    __syncthreads();  // all tiles consumed, nothing in flight: the stages become the epilogue's staging space
+    // ---- epilogue ---------------------------------------------------------------------------------------------------------
+    // The MFMA C/D layout gives a lane one column and 16 scattered rows: storing from it means 2- or 4-byte stores in 64/128-byte
+    // runs, which bounds the short-K GEMMs (K = 512..768: 8-12 K-steps per 128x128 output tile).  Each wave therefore transposes its
+    // 64x64 block through its own 16 KB of the (now free) LDS, 32 rows at a time, and writes 16 bytes per lane along the rows; bias /
+    // bf16 rounding / GELU are applied on the way in, the fp32 residual on the way out.
+    constexpr int EP = 68;  // floats per staged row (64 + 4: 16-byte aligned rows, conflict-light)
+    const int ldc_e = g.ldc, n_valid = g.N - (bn0 + wn * 64);
+    if (EPI != 0 || !g.vec_epi) {
+        gemm_epilogue<EPI, false>(g, acc, bm0, bn0, wm, wn, lr, lh);
+        return;
+    }
+    // every wave is past the last barrier: both stages are free; a wave stages 32 rows x 68 floats = 8.5 KB
+    float *stg = reinterpret_cast<float *>((wave < WM ? lds0 : lds1) + (wave % WM) * (STAGE / WM));
     const bool do_gelu = g.flags & ACAI_GEMM_GELU, do_round = g.flags & ACAI_GEMM_ROUND_BF16;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -427,8 +653,18 @@ int launch(const GemmArgs &g, hipStream_t st) {
     h.vec_epi = (EPI == 0) && (g.ldc % 8 == 0) && (g.N % 8 == 0) && aligned16(g.C) && (!g.residual || (g.ldr % 4 == 0 && aligned16(g.residual)));
     constexpr int BKG = ROWB / (int)sizeof(T);
     static const bool no_glds = getenv("ACAI_GEMM_NO_GLDS") != nullptr;
-    if (fast && !TA && !TB && g.K % BKG == 0 && !no_glds)
-        hipLaunchKernelGGL((gemm_nt_glds_kernel<T, EPI>), dim3(nwg), dim3(256), 0, st, h);
+    static const char *force_wm = getenv("ACAI_GEMM_WM");   // A/B aid: "2" or "4"
+    if (fast && !TA && !TB && g.K % BKG == 0 && !no_glds) {
+        const int nwg4 = cdiv(g.M, 256) * cdiv(g.N, BN);
+        const bool big = force_wm ? atoi(force_wm) == 4 : nwg4 >= 512;
+        static const bool no3 = getenv("ACAI_GEMM_NO_3STAGE") != nullptr;
+        if (big && !no3)
+            hipLaunchKernelGGL((gemm_nt_glds3_kernel<T, EPI>), dim3(nwg4), dim3(512), 0, st, h);
+        else if (big)
+            hipLaunchKernelGGL((gemm_nt_glds_kernel<T, EPI, 4>), dim3(nwg4), dim3(512), 0, st, h);
+        else
+            hipLaunchKernelGGL((gemm_nt_glds_kernel<T, EPI, 2>), dim3(nwg), dim3(256), 0, st, h);
+    }
     else if (fast)
         hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, true, TA, TB>), dim3(nwg), dim3(256), 0, st, h);
     else

@@ -37,6 +37,20 @@ def test_layernorm(dev, rows, dim):
 @pytest.mark.parametrize("M,N,K", [(300, 200, 96), (128, 128, 64), (37, 19, 10), (1, 227, 1024), (513, 768, 256), (260, 130, 72)])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_gemm_nt(dev, M, N, K, dtype):
+    _check_gemm_nt(dev, M, N, K, dtype)
+
+
+@pytest.mark.parametrize("K", [64, 128, 192, 256, 320, 704])
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_gemm_nt_three_stage_tile(dev, K, dtype):
+    """Shapes with >= 512 tiles of 256x128 take the three-stage LDS-DMA kernel (two K-tiles in flight, counted vmcnt waits): every K-tile
+    count modulo 3, one to many tiles, ragged M / N edges."""
+    if dtype == "fp32":
+        K //= 2   # 32 floats per K-tile: same tile counts
+    _check_gemm_nt(dev, 16384 + 40, 4096 + 24, K, dtype)
+
+
+def _check_gemm_nt(dev, M, N, K, dtype):
     from acai_omr_amd import ops
     g = torch.Generator().manual_seed(M + N + K)
     a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
