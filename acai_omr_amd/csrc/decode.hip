@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             wf[c] = make_uint4(0, 0, 0, 0);
-            if (c < nch && row_ok) wf[c] = ld_nt16(Wrow + 32 * c);
+            if (c < nch && row_ok) wf[c] = (a.ablate & 8) ? *reinterpret_cast<const uint4 *>(Wrow + 32 * c) : ld_nt16(Wrow + 32 * c);
         }
         // 1b. wave 0 also fetches everything its epilogue needs now, so that nothing is loaded after the reduction
         float e_bias[4] = {0.f, 0.f, 0.f, 0.f}, e_res[4] = {0.f, 0.f, 0.f, 0.f}, e_rw[4] = {1.f, 1.f, 1.f, 1.f}, e_rb[4] = {0.f, 0.f, 0.f, 0.f};
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
             for (int c = 0; c < 8; ++c) {  // next batch of weight fragments (none when NW covers K in one batch)
                 wn[c] = make_uint4(0, 0, 0, 0);
                 if constexpr (NW * 256 < SKM_MAXK)
-                    if (c0 + 8 + c < nch && row_ok) wn[c] = ld_nt16(Wrow + 32 * (c0 + 8 + c));
+                    if (c0 + 8 + c < nch && row_ok) wn[c] = (a.ablate & 8) ? *reinterpret_cast<const uint4 *>(Wrow + 32 * (c0 + 8 + c)) : ld_nt16(Wrow + 32 * (c0 + 8 + c));
             }
 #pragma unroll
             for (int c = 0; c < 8; ++c)
@@ -396,6 +396,10 @@ int launch_skinny(const SkinnyArgs &a, hipStream_t st) {
             static const int abl = getenv("ACAI_SKINNY_ABLATE") ? atoi(getenv("ACAI_SKINNY_ABLATE")) : 0;
             static const int rpb = getenv("ACAI_SKINNY_ROWS") ? atoi(getenv("ACAI_SKINNY_ROWS")) : 0;
             b.ablate = abl;
+            // weight cache policy (A/B aid): 0 = default-policy loads for every matrix, 2 = default policy below 8 MB (candidates for the
+            // Infinity Cache across steps) and non-temporal above, unset = non-temporal everywhere
+            static const int ntm = getenv("ACAI_SKINNY_NT") ? atoi(getenv("ACAI_SKINNY_NT")) : 1;
+            if (ntm == 0 || (ntm == 2 && (size_t)a.N * a.K * 2 < (8u << 20))) b.ablate |= 8;
             b.rows_per_block = rpb ? rpb : (a.N >= 2560 ? 16 : (a.N >= 1600 ? 8 : 4));
             const dim3 grid(cdiv(a.N, b.rows_per_block));
             if (wide)

@@ -181,6 +181,51 @@ def test_teacher_forced_train_step_vs_reference(dev, name):
         assert md(params[n].grad, gref) < 3e-4 * max(1.0, float(gref.abs().max())), n
 
 
+def test_scheduled_sampling_forward_train(dev):
+    """ScheduledSamplingViTOMR.forward_train (models.py:798-838): with teacher_forcing_prob = 1 no position is sampled, the second decoder
+    pass sees the gold embeddings and the step must equal the reference's teacher-forced golden step (pred, loss, gradients); with
+    probability 0 every position takes the Gumbel-softmax expectation of the first pass, whose graph then carries gradient too."""
+    from acai_omr_amd.models.models import FineTuneOMREncoder, OMRCELoss, OMRDecoder, ScheduledSamplingViTOMR
+    fx = load_golden("tf_small")
+    cfg = fx["cfg"]
+
+    def build():
+        enc = FineTuneOMREncoder(cfg["P"], cfg["pe_h"], cfg["pe_w"], cfg["ft_depth"], num_layers=cfg["enc_layers"], hidden_dim=cfg["enc_dim"],
+                                 num_heads=cfg["enc_heads"], mlp_dim=cfg["enc_mlp"], transformer_dropout=0.0)
+        dec = OMRDecoder(cfg["max_len"], VOCAB, num_layers=cfg["dec_layers"], hidden_dim=cfg["dec_dim"], num_heads=cfg["dec_heads"], mlp_dim=cfg["dec_mlp"],
+                         transformer_dropout=0.0)
+        m = ScheduledSamplingViTOMR(enc, None, dec, transition_head_dim=cfg["head_dim"], transition_head_dropout=0.0)
+        m.load_state_dict(fx["state_dict"])
+        return m.to(dev).train()
+
+    batch = list(zip(fx["imgs"], fx["lmx"]))
+    m = build()
+    pred, tgt = m.forward_train(batch, 1.0, 0.5, False)
+    valid = fx["target"] != 1
+    assert torch.equal(tgt.cpu(), fx["target"]) and md(pred.cpu()[valid], fx["pred"][valid]) < 1e-3
+    loss = OMRCELoss(m.decoder.pad_idx)(pred, tgt)
+    assert abs(float(loss) - float(fx["loss"])) < 1e-4
+    loss.backward()
+    params = dict(m.named_parameters())
+    for n, gref in fx["grads"].items():
+        assert md(params[n].grad, gref) < 3e-4 * max(1.0, float(gref.abs().max())), n
+    g_gold = {n: p.grad.clone() for n, p in params.items() if p.grad is not None}
+    # every position sampled: finite, seeded, and a different gradient (the first pass contributes through the soft sample)
+    m2 = build()
+    torch.manual_seed(3)
+    pred2, _ = m2.forward_train(batch, 0.0, 0.5, False)
+    loss2 = OMRCELoss(m2.decoder.pad_idx)(pred2, tgt)
+    loss2.backward()
+    assert torch.isfinite(pred2).all() and abs(float(loss2) - float(loss)) > 1e-5
+    g2 = {n: p.grad for n, p in m2.named_parameters() if p.grad is not None}
+    assert all(torch.isfinite(v).all() for v in g2.values())
+    assert md(g2["decoder.unembed.weight"], g_gold["decoder.unembed.weight"]) > 1e-6
+    torch.manual_seed(3)
+    pred3, _ = build().forward_train(batch, 0.0, 0.5, False)
+    assert md(pred3, pred2) < 1e-5          # same seed, same sample
+    assert torch.equal(m2.forward_eval(batch)[1].cpu(), fx["target"])
+
+
 def test_dropout_kernels(dev):
     """Counter-based dropout: keep rate / scaling, forward-backward mask consistency, attention-probability dropout checked against
     finite differences of the forward kernel itself (same seed -> same mask) and in expectation against the undropped output."""
