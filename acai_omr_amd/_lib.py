@@ -24,6 +24,14 @@ class AcaiDecLayer(Structure):
         "k_self", "v_self", "k_cross", "v_cross")]
 
 
+class AcaiAdamWTensor(Structure):
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64), ("group", c_int32), ("pad_", c_int32)]
+
+
+class AcaiAdamWGroup(Structure):
+    _fields_ = [(n, c_float) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "bias_c1", "bias_c2_sqrt", "pad_")]
+
+
 class AcaiDecoder(Structure):
     _fields_ = [(n, c_int32) for n in (
         "B", "E", "H", "dh", "dhp", "F", "V", "L", "Tmax", "dtype", "flags", "max_len",
@@ -54,6 +62,7 @@ _SIGNATURES = {
     "acai_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "acai_gelu_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "acai_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "acai_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "acai_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "acai_scatter_add_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "acai_mae_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),

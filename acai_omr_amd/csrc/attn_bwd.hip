@@ -48,12 +48,13 @@ __device__ __forceinline__ uint4 ld16(const T *base, int ld, int row, int rows, 
     return r;
 }
 
-// acc (32 x 32, rows in registers) += A(LDS rows, contraction-contiguous) . B(register fragments)
-template <typename T, int NS>
-__device__ __forceinline__ void mma_rows(f32x16 &acc, const unsigned char *a_rows, int pitch, int lr, int lh, const uint4 (&bf)[NS]) {
+// acc (32 x 32, rows in registers) += A(rows r0.. of an LDS tile, contraction-contiguous) . B(register fragments)
+template <typename T, int DHP, int NS>
+__device__ __forceinline__ void mma_rows(f32x16 &acc, const unsigned char *tile, int r0, int lr, int lh, const uint4 (&bf)[NS]) {
+    typedef TileLayout<sizeof(T), DHP> TL;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const uint4 af = *reinterpret_cast<const uint4 *>(a_rows + lr * pitch + s * 32 + lh * 16);
+        const uint4 af = *reinterpret_cast<const uint4 *>(tile + TL::off(r0 + lr, 2 * s + lh));
         if constexpr (sizeof(T) == 2) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf[s]), acc, 0, 0, 0);
         } else {
@@ -68,8 +69,10 @@ __device__ __forceinline__ void mma_rows(f32x16 &acc, const unsigned char *a_row
 // the 32 output rows are its columns c0..c0+31; X is a 32x32 accumulator tile whose register rows are the contraction rows.
 // bf16: two 4-row x 16-col transposing reads (ds_read_b64_tr_b16) build the A fragment whose element j is contraction row
 // 16 s2 + 8 (j>>2) + 4 lh + (j&3) - the order of X's registers 8 s2 + j.  fp32: one ds_read_b32 per K=2 MFMA.
-template <typename T>
-__device__ __forceinline__ void mma_acc(f32x16 &acc, const unsigned char *tile, int pitch, int r0, int c0, int lane, const f32x16 &x) {
+template <typename T, int DHP>
+__device__ __forceinline__ void mma_acc(f32x16 &acc, const unsigned char *tile, int r0, int c0, int lane, const f32x16 &x) {
+    typedef TileLayout<sizeof(T), DHP> TL;
+    constexpr int pitch = TL::PITCH;
     const int lr = lane & 31, lh = lane >> 5;
     if constexpr (sizeof(T) == 2) {
         typedef __attribute__((ext_vector_type(4))) short s4;
@@ -82,10 +85,10 @@ __device__ __forceinline__ void mma_acc(f32x16 &acc, const unsigned char *tile, 
             xf.y = pack_bf16(x[8 * s2 + 2], x[8 * s2 + 3]);
             xf.z = pack_bf16(x[8 * s2 + 4], x[8 * s2 + 5]);
             xf.w = pack_bf16(x[8 * s2 + 6], x[8 * s2 + 7]);
-            const unsigned char *p = tile + (r0 + 16 * s2 + 4 * lh + (i16 >> 2)) * pitch + (c0 + 16 * g1 + 4 * (i16 & 3)) * 2;
+            const int row = r0 + 16 * s2 + 4 * lh + (i16 >> 2), chunk = (c0 >> 3) + 2 * g1 + ((i16 & 3) >> 1), sub = 8 * (i16 & 1);
             union { s4 v[2]; uint4 u; } af;
-            af.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p));
-            af.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p + 8 * pitch));
+            af.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(tile + TL::off(row, chunk) + sub));
+            af.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(tile + TL::off(row + 8, chunk) + sub));
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af.u), __builtin_bit_cast(bf16x8, xf), acc, 0, 0, 0);
         }
     } else {
@@ -103,7 +106,8 @@ __device__ __forceinline__ void mma_acc(f32x16 &acc, const unsigned char *tile, 
 // costs one barrier.  Per-thread global pointers advance by one tile per call; interior tiles load unguarded.
 template <typename T, int DHP, bool FAST>
 struct TileStager {
-    static constexpr int ES = sizeof(T), EPC = 16 / ES, RP = DHP * ES + 16, CPR = DHP / EPC, NCH = 64 * CPR / 256;
+    typedef TileLayout<sizeof(T), DHP> TL;
+    static constexpr int ES = sizeof(T), EPC = 16 / ES, RP = TL::PITCH, CPR = DHP / EPC, NCH = 64 * CPR / 256;
     const T *pa[NCH], *pb[NCH], *A, *B;
     int srow[NCH], soff[NCH], lda, ldb, dh;
     bool dok[NCH];
@@ -114,7 +118,7 @@ struct TileStager {
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + 256 * i, row = c / CPR, cc = c % CPR;
             srow[i] = row;
-            soff[i] = row * RP + cc * 16;
+            soff[i] = TL::off(row, cc);
             dok[i] = cc * EPC < dh;
             pa[i] = A + ((size_t)first_tile * 64 + row) * lda + cc * EPC;
             pb[i] = B + ((size_t)first_tile * 64 + row) * ldb + cc * EPC;
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T *o, int ldo, co
 template <typename T, int DHP, bool FAST, bool DROP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dq_kernel(BwdArgs a) {
     constexpr int ES = sizeof(T);
-    constexpr int RP = DHP * ES + 16;   // pitch of the natural [row][d] tiles
+    constexpr int RP = TileLayout<ES, DHP>::PITCH;   // pitch of the natural [row][d] tiles
     constexpr int NS = DHP * ES / 32, NDB = DHP / 32, STAGE = 2 * TT * RP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // two stages of {K tile, V tile}
 
@@ -227,11 +231,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         const bool interior = (kt + 1) * TT <= (a.causal ? min(lk, q0 + wave * 32 + 1) : lk);  // every key valid for the whole wave
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            // without dropout the accumulator of dP starts at -delta (a per-lane scalar here): dP - delta leaves the MFMA for free
             f32x16 sacc, dpacc;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sacc[e] = dpacc[e] = 0.f;
-            mma_rows<T, NS>(sacc, ldsK + kb * 32 * RP, RP, lr, lh, qf);     // S^T[key][q]
-            mma_rows<T, NS>(dpacc, ldsV + kb * 32 * RP, RP, lr, lh, dof);   // dP^T[key][q]
+            for (int e = 0; e < 16; ++e) {
+                sacc[e] = 0.f;
+                dpacc[e] = DROP ? 0.f : -dlt;
+            }
+            mma_rows<T, DHP, NS>(sacc, ldsK, kb * 32, lr, lh, qf);     // S^T[key][q]
+            mma_rows<T, DHP, NS>(dpacc, ldsV, kb * 32, lr, lh, dof);   // dP^T[key][q] (- delta)
             if constexpr (DROP) {  // dP = mask/(1-p) o (dO V^T)
                 const uint32_t rrow = (uint32_t)(h * a.total_q + q_start + my_q);
 #pragma unroll
@@ -240,19 +248,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                     dpacc[e] = drop_keep(a.drop_seed, rrow, key, a.drop_thr) ? dpacc[e] * a.drop_scale : 0.f;
                 }
             }
+            const float dsub = DROP ? dlt : 0.f;
             if (interior) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) sacc[e] = fast_exp2(fmaf(sacc[e], a.scale_log2e, -lse)) * (dpacc[e] - dlt);   // dS^T
+                for (int e = 0; e < 16; ++e) sacc[e] = fast_exp2(fmaf(sacc[e], a.scale_log2e, -lse)) * (dpacc[e] - dsub);   // dS^T
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int key = kt * TT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                     const float p = key < key_lim ? fast_exp2(sacc[e] * a.scale_log2e - lse) : 0.f;
-                    sacc[e] = p * (dpacc[e] - dlt);                        // dS^T
+                    sacc[e] = p * (dpacc[e] - dsub);                        // dS^T
                 }
             }
 #pragma unroll
-            for (int d = 0; d < NDB; ++d) mma_acc<T>(dqacc[d], ldsK, RP, kb * 32, d * 32, lane, sacc);  // dQ^T += K^T dS^T
+            for (int d = 0; d < NDB; ++d) mma_acc<T, DHP>(dqacc[d], ldsK, kb * 32, d * 32, lane, sacc);  // dQ^T += K^T dS^T
         }
         if (kt + 1 < nkt) stg.store(smem + ((kt + 1) & 1) * STAGE);
         __syncthreads();
@@ -271,9 +280,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename T, int DHP, bool FAST, bool DROP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DHP == 64) ? 1 : 2))) void attn_bwd_dkv_kernel(BwdArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DHP == 64) ? 1 : ((sizeof(T) == 2 && DHP == 32) ? 3 : 2)))) void attn_bwd_dkv_kernel(BwdArgs a) {
     constexpr int ES = sizeof(T);
-    constexpr int RP = DHP * ES + 16;
+    constexpr int RP = TileLayout<ES, DHP>::PITCH;
     constexpr int NS = DHP * ES / 32, NDB = DHP / 32, STAGE = 2 * TT * RP + 2 * TT * (int)sizeof(float);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // two stages of {Q tile, dO tile, lse[64], delta[64]}
 
@@ -340,11 +349,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) 
         }
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            f32x16 sacc, dpacc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sacc[e] = dpacc[e] = 0.f;
-            mma_rows<T, NS>(sacc, ldsQ + qb * 32 * RP, RP, lr, lh, kf);      // S[q][key]
-            mma_rows<T, NS>(dpacc, ldsDO + qb * 32 * RP, RP, lr, lh, vf);    // dP[q][key]
             // row statistics of the 16 query rows this lane holds: rows 8 g4 + 4 lh + (0..3) are contiguous -> one 16-byte LDS read each
             f32x4 lse4[4], dlt4[4];
 #pragma unroll
@@ -352,6 +356,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) 
                 lse4[g4] = *reinterpret_cast<const f32x4 *>(ldsLse + qb * 32 + 8 * g4 + 4 * lh);
                 dlt4[g4] = *reinterpret_cast<const f32x4 *>(ldsDlt + qb * 32 + 8 * g4 + 4 * lh);
             }
+            // without dropout the dP accumulator starts at -delta[row]: dP - delta leaves the MFMA for free
+            f32x16 sacc, dpacc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                sacc[e] = 0.f;
+                dpacc[e] = DROP ? 0.f : -dlt4[e >> 2][e & 3];
+            }
+            mma_rows<T, DHP, NS>(sacc, ldsQ, qb * 32, lr, lh, kf);      // S[q][key]
+            mma_rows<T, DHP, NS>(dpacc, ldsDO, qb * 32, lr, lh, vf);    // dP[q][key] (- delta)
             // interior: every query of the tile exists, every key of the WAVE exists and (causal) lies at or before the tile's first query
             const bool interior = (qt + 1) * TT <= lq && k0 + wave * 32 + 32 <= lk && (!a.causal || k0 + wave * 32 + 31 <= qt * TT + qb * 32);
             if (DROP) {  // keep mask of (query row, my key): dP is masked, and so is the P that multiplies dO for dV
@@ -369,7 +382,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) 
                 for (int e = 0; e < 16; ++e) {
                     const float p = fast_exp2(fmaf(sacc[e], a.scale_log2e, -lse4[e >> 2][e & 3]));
                     sacc[e] = p;                                           // P
-                    dpacc[e] = p * (dpacc[e] - dlt4[e >> 2][e & 3]);       // dS
+                    dpacc[e] = p * dpacc[e];                               // dS (delta already subtracted)
                 }
             } else {
 #pragma unroll
@@ -378,13 +391,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) 
                     const bool ok = qq < lq && my_k < lk && (!a.causal || my_k <= qq);
                     const float p = ok ? fast_exp2(sacc[e] * a.scale_log2e - lse4[e >> 2][e & 3]) : 0.f;
                     sacc[e] = p;
-                    dpacc[e] = p * (dpacc[e] - dlt4[e >> 2][e & 3]);
+                    dpacc[e] = p * dpacc[e];
                 }
             }
 #pragma unroll
             for (int d = 0; d < NDB; ++d) {
-                mma_acc<T>(dvacc[d], ldsDO, RP, qb * 32, d * 32, lane, sacc);   // dV^T += dO^T P
-                mma_acc<T>(dkacc[d], ldsQ, RP, qb * 32, d * 32, lane, dpacc);   // dK^T += Q^T dS
+                mma_acc<T, DHP>(dvacc[d], ldsDO, qb * 32, d * 32, lane, sacc);   // dV^T += dO^T P
+                mma_acc<T, DHP>(dkacc[d], ldsQ, qb * 32, d * 32, lane, dpacc);   // dK^T += Q^T dS
             }
         }
         if (qt + 1 < nqt) {
@@ -414,7 +427,7 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, hipStream_t st) {
     constexpr int ES = sizeof(T), EPC = 16 / ES;
     const bool fast = (a.dh % EPC == 0) && (a.ldq % EPC == 0) && (a.ldk % EPC == 0) && (a.ldv % EPC == 0) && (a.lddo % EPC == 0) &&
                       aligned16(a.q) && aligned16(a.k) && aligned16(a.v) && aligned16(a.dout);
-    constexpr int RP = DHP * ES + 16;
+    constexpr int RP = TileLayout<ES, DHP>::PITCH;
     const size_t lds_dq = 2 * (2 * TT * RP), lds_dkv = 2 * (2 * TT * RP + 2 * TT * sizeof(float));   // two stages each
     auto launch_pair = [&](auto drop, auto fst) {
         constexpr bool D = decltype(drop)::value, F = decltype(fst)::value;

@@ -37,7 +37,8 @@ template <typename T, int DHP, bool FAST, bool DROP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_fwd_kernel(AttnArgs a) {
     constexpr int ES = sizeof(T);
     constexpr int EPC = 16 / ES;                 // elements per 16-byte chunk
-    constexpr int KPITCH = DHP * ES + 16;        // bytes per K / V row in LDS (both tiles keep their natural [key][d] image)
+    typedef TileLayout<ES, DHP> TL;              // natural [key][d] image of the K and V tiles (swizzled bf16 / padded fp32)
+    constexpr int KPITCH = TL::PITCH;
     constexpr int NS = DHP * ES / 32;            // 16-byte fragments per lane along d (per lane-half)
     constexpr int NDB = DHP / 32;                // 32-wide d blocks of the output
     constexpr int CPR = DHP / EPC;               // 16-byte chunks per K/V row
@@ -87,6 +88,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
     float m_run = -1.0e30f, l_run = 0.f;  // running max (scaled, log2 domain) and this lane-half's partial sum
+    // Row sums stay on the VALU.  Measured alternative (kept behind MFMA_SUM): one extra MFMA per 16 keys with an all-ones A operand
+    // replaces the 32 adds per tile, but the kernel got 20 % SLOWER (2.0 -> 2.46 ms at d_h = 32): the four dependent MFMAs per tile on one
+    // accumulator hold the wave's issue port longer than the adds they replace.
+    constexpr bool MFMA_SUM = false;
+    f32x16 lacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
 
     int nkt = (lk + KT - 1) / KT;
     if (a.causal) {
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     for (int i = 0; i < NCH; ++i) {
         const int c = tid + 256 * i, row = c / CPR, cc = c % CPR;
         srow[i] = row;
-        soff[i] = row * KPITCH + cc * 16;
+        soff[i] = TL::off(row, cc);
         dok[i] = cc * EPC < dh;
         kp[i] = K + (size_t)row * a.ldk + cc * EPC;
         vp[i] = V + (size_t)row * a.ldv + cc * EPC;
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
             for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                const uint4 kf = *reinterpret_cast<const uint4 *>(ldsK + (kb * 32 + lr) * KPITCH + s * 32 + lh * 16);
+                const uint4 kf = *reinterpret_cast<const uint4 *>(ldsK + TL::off(kb * 32 + lr, 2 * s + lh));
                 if constexpr (ES == 2) {
                     sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
                                                                        __builtin_bit_cast(bf16x8, qf[s]), sacc[kb], 0, 0, 0);
@@ -179,6 +187,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                 const float alpha = fast_exp2(m_run - m2);
                 m_run = m2;
                 l_run *= alpha;
+                lacc[0] *= alpha;
 #pragma unroll
                 for (int d = 0; d < NDB; ++d)
 #pragma unroll
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                 for (int e = 0; e < 16; ++e) {
                     const float p = fast_exp2(fmaf(sacc[kb][e], a.scale_log2e, -m_new));
                     sacc[kb][e] = p;
-                    psum += p;
+                    if constexpr (!MFMA_SUM) psum += p;
                 }
         } else {
             float tmax = -1.0e30f;
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                     // masked entries: gate on the mask value itself (a fully masked row keeps m = -1e30 and exp2(0) = 1 would be wrong)
                     const float p = sacc[kb][e] > -0.5e30f ? fast_exp2(sacc[kb][e] - m_new) : 0.f;
                     sacc[kb][e] = p;
-                    psum += p;
+                    if constexpr (!MFMA_SUM) psum += p;
                 }
         }
         l_run += psum;
@@ -248,6 +257,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                     pf.y = pack_bf16(sacc[kb][8 * s2 + 2], sacc[kb][8 * s2 + 3]);
                     pf.z = pack_bf16(sacc[kb][8 * s2 + 4], sacc[kb][8 * s2 + 5]);
                     pf.w = pack_bf16(sacc[kb][8 * s2 + 6], sacc[kb][8 * s2 + 7]);
+                    if constexpr (MFMA_SUM) {
+                        const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);  // bf16 1.0 x 8
+                        lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf), lacc, 0, 0, 0);
+                    }
 #pragma unroll
                     for (int d = 0; d < NDB; ++d) {
                         // A element j = V[key 16 s2 + 8 (j>>2) + 4 lh + (j&3)][d]: two 4-key x 16-d transposing reads of the natural V tile
@@ -255,10 +268,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                         typedef __attribute__((ext_vector_type(4))) short s4;
                         typedef __attribute__((address_space(3))) s4 *lds_s4;
                         const int i16 = lane & 15, g1 = (lane >> 4) & 1;
-                        const unsigned char *vr = ldsV + (kb * 32 + 16 * s2 + 4 * lh + (i16 >> 2)) * KPITCH + (d * 32 + 16 * g1 + 4 * (i16 & 3)) * 2;
+                        const int vrow = kb * 32 + 16 * s2 + 4 * lh + (i16 >> 2), vchunk = d * 4 + 2 * g1 + ((i16 & 3) >> 1), vsub = 8 * (i16 & 1);
                         union { s4 v[2]; uint4 u; } vf;
-                        vf.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(vr));
-                        vf.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(vr + 8 * KPITCH));
+                        vf.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(ldsV + TL::off(vrow, vchunk) + vsub));
+                        vf.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(ldsV + TL::off(vrow + 8, vchunk) + vsub));
                         oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf.u),
                                                                          __builtin_bit_cast(bf16x8, pf), oacc[d], 0, 0, 0);
                     }
@@ -282,7 +295,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     }
 
     // ---- normalise and store: lane owns query my_q, registers hold d = db*32 + (e&3) + 8*(e>>2) + 4*lh ------
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    // MFMA row sums: every lane of a column holds the complete sum over all keys (both lane halves)
+    const float l_tot = MFMA_SUM ? lacc[0] : l_run + __shfl_xor(l_run, 32);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (a.lse && my_q < lq && lh == 0) a.lse[(size_t)h * a.total_q + q_start + my_q] = m_run + log2f(l_tot);
     if (my_q < lq) {

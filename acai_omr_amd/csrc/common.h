@@ -64,6 +64,23 @@ __device__ __forceinline__ uint4 ld_nt16(const void *p) {
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
+// LDS image of a [rows][DHP] attention operand tile (K, V, Q, dO) in its natural row-major order.
+//   bf16: unpadded rows (64 / 128 bytes) with an XOR swizzle of the 16-byte chunk index by row bits, chosen so that BOTH access patterns are
+//         bank-conflict free: ds_read_b128 of one chunk column by 16 consecutive rows, and ds_read_b64_tr_b16 of a 4-row x 64-byte block.
+//         (The padded pitch used before cost 25-38 % of the LDS cycles in conflicts on the transposing reads - PMC SQ_LDS_BANK_CONFLICT.)
+//   fp32: rows padded by 16 bytes (the K=2 MFMA path reads single floats down a column).
+template <int ES, int DHP>
+struct TileLayout {
+    static constexpr int PITCH = ES == 2 ? DHP * 2 : DHP * 4 + 16;
+    __device__ static __forceinline__ int swz(int row) {
+        if constexpr (ES != 2) return 0;
+        else if constexpr (DHP == 32) return (row >> 2) & 3;
+        else return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+    }
+    // byte offset of 16-byte chunk `chunk` of row `row`
+    __device__ static __forceinline__ int off(int row, int chunk) { return row * PITCH + ((chunk ^ swz(row)) << 4); }
+};
+
 // exact-erf GELU, as torch's F.gelu(approximate="none")
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

@@ -1,0 +1,91 @@
+"""Fused multi-tensor AdamW for the training steps of the path.
+
+Drop-in for `torch.optim.AdamW` as the reference uses it (`acai_omr/train/pre_train.py:105`: one group, lr 1.5e-4, betas (0.9, 0.95), weight
+decay 0.05; `acai_omr/train/omr_teacher_force_train.py:207`: the layer-wise-LR param groups of `acai_omr/models/models.py:761-781`): same
+constructor arguments, same `state_dict()` layout (`step`, `exp_avg`, `exp_avg_sq` per parameter), `param_groups[i]["lr"]` is read every step so
+torch LR schedulers (the reference's `LambdaLR`-style cosine/warm-up, `acai_omr/utils/utils.py:204-222`) drive it unchanged.  One HIP launch
+(`acai_adamw_step`) updates all tensors; there is no CPU fallback."""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+
+CHUNK = 16384  # elements per workgroup
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, maximize=False):
+        if amsgrad or maximize:
+            raise NotImplementedError("FusedAdamW: amsgrad / maximize are not used by the reference and not built")
+        if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
+            raise ValueError("FusedAdamW: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._layout = None  # (key, tensors_dev, chunk_tensor_dev, chunk_off_dev, n_chunks, holders)
+
+    # ---- tables -----------------------------------------------------------------------------------------------------------------------
+    def _active(self):
+        out = []
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse or p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_cuda:
+                    raise RuntimeError("FusedAdamW: dense fp32 parameters and gradients on the GPU only")
+                if not (p.is_contiguous() and p.grad.is_contiguous()):
+                    raise RuntimeError("FusedAdamW: parameters and gradients must be contiguous")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                out.append((gi, p, st))
+        return out
+
+    def _build(self, active, dev):
+        key = tuple((gi, p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()) for gi, p, st in active)
+        if self._layout is not None and self._layout[0] == key:
+            return self._layout
+        arr = (_lib.AcaiAdamWTensor * len(active))()
+        ct, co = [], []
+        for i, (gi, p, st) in enumerate(active):
+            arr[i].p, arr[i].g, arr[i].m, arr[i].v = p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            arr[i].n, arr[i].group = p.numel(), gi
+            for off in range(0, p.numel(), CHUNK):
+                ct.append(i)
+                co.append(off)
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self._layout = (key, raw, torch.tensor(ct, dtype=torch.int32).to(dev), torch.tensor(co, dtype=torch.int64).to(dev), len(ct))
+        return self._layout
+
+    # ---- step ---------------------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        active = self._active()
+        if not active:
+            return loss
+        dev = active[0][1].device
+        steps = {}
+        for gi, p, st in active:
+            st["step"] += 1
+            steps.setdefault(gi, float(st["step"]))
+            if float(st["step"]) != steps[gi]:
+                raise RuntimeError("FusedAdamW: parameters of one group must share their step count")
+        garr = (_lib.AcaiAdamWGroup * len(self.param_groups))()
+        for gi, group in enumerate(self.param_groups):
+            t = steps.get(gi, 1.0)
+            b1, b2 = group["betas"]
+            garr[gi].lr, garr[gi].beta1, garr[gi].beta2, garr[gi].eps = float(group["lr"]), b1, b2, group["eps"]
+            garr[gi].weight_decay, garr[gi].bias_c1, garr[gi].bias_c2_sqrt = group["weight_decay"], 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t)
+        gdev = torch.frombuffer(bytearray(bytes(garr)), dtype=torch.uint8).to(dev)
+        _, tdev, ctd, cod, n_chunks = self._build(active, dev)
+        with torch.cuda.device(dev):
+            st_ = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib.check(_lib.lib().acai_adamw_step(tdev.data_ptr(), gdev.data_ptr(), ctd.data_ptr(), cod.data_ptr(), n_chunks, CHUNK, float(grad_scale), st_),
+                       "acai_adamw_step")
+        return loss

@@ -90,15 +90,18 @@ def cpu_baseline(vitomr, lens, steps):
 def bench_mae(dev, rank, world, dist, batch, height, width, steps, dtype):
     """Second half of the BASELINE.json metric: MAE images/sec = images / (forward + MAELoss + backward [+ DP gradient
     all-reduce]) on `batch` synthetic HxW images per GPU, full-size MAE(0.75, 16, 60, 200) (pre_train.py:156-159).
-    The optimizer step is not included (AdamW is stock torch in the reference; a fused one is SURVEY 8f)."""
+    The step ends with the optimizer update (pre_train.py:59-61: AdamW lr 1.5e-4, betas (0.9, 0.95), weight decay 0.05) through the fused
+    multi-tensor AdamW kernel."""
     from torch.amp import autocast
 
     from acai_omr_amd.config import MASK_RATIO, PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH
     from acai_omr_amd.dist import GradAllReduce, global_mean_scale
     from acai_omr_amd.models.models import MAE, MAELoss
+    from acai_omr_amd.optim import FusedAdamW
     torch.manual_seed(0)
     mae = MAE(MASK_RATIO, PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH).to(dev).train()
     ddp = GradAllReduce(mae) if world > 1 else None
+    opt = FusedAdamW(mae.parameters(), lr=1.5e-4, betas=(0.9, 0.95), weight_decay=0.05)
     g = torch.Generator().manual_seed(2000 + rank)
     imgs = [torch.rand(1, height, width, generator=g).to(dev) for _ in range(batch)]
     data = list(zip(imgs, imgs))
@@ -117,6 +120,7 @@ def bench_mae(dev, rank, world, dist, batch, height, width, steps, dtype):
         loss.backward()
         if ddp is not None:
             ddp.finish()
+        opt.step()
         return loss
 
     step()
@@ -136,10 +140,10 @@ def bench_mae(dev, rank, world, dist, batch, height, width, steps, dtype):
         dt = float(t.item())
     flop_img = 2.29e12 * (height * width) / (512 * 2048) if (height, width) == (512, 2048) else None
     out = dict(images_per_s=world * batch * steps / dt, ms_per_step=dt / steps * 1e3, batch_per_gpu=batch, image=f"{height}x{width}", dtype=dtype,
-               steps=steps, includes="forward + MAELoss + backward" + (" + RCCL gradient all-reduce" if world > 1 else ""), loss=float(loss))
+               steps=steps, includes="forward + MAELoss + backward" + (" + RCCL gradient all-reduce" if world > 1 else "") + " + fused AdamW step", loss=float(loss))
     if flop_img:
         out["tflops_algorithmic"] = flop_img * world * batch * steps / dt / 1e12
-    del mae, ddp
+    del mae, ddp, opt
     torch.cuda.empty_cache()
     return out
 

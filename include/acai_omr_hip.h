@@ -116,6 +116,25 @@ int acai_mae_loss(const float *pred, const float *target, const unsigned char *m
 int acai_ce_loss(const float *logits, int ld, const int64_t *target, int ignore_index, float inv_count, float *loss, float *dlogits,
                  int rows, int V, void *stream);
 
+/* Fused multi-tensor AdamW: one launch steps every parameter tensor (reference: torch.optim.AdamW in acai_omr/train/pre_train.py:105 and
+ * omr_teacher_force_train.py:207 over the param groups of acai_omr/models/models.py:761-781; the cosine/warm-up schedule of
+ * acai_omr/utils/utils.py:204-222 only changes `lr`).  All tables live in DEVICE memory.  tensors[i]: fp32 parameter, gradient and the two
+ * moment buffers (n elements) + the index of its hyper-parameter group; groups[j]: this step's lr, betas, eps, weight decay and bias
+ * corrections bc1 = 1 - beta1^t, sqrt(bc2) = sqrt(1 - beta2^t).  chunk_tensor / chunk_off: one entry per workgroup = (tensor, first element)
+ * of a chunk of chunk_elems (multiple of 4) elements.  grad_scale multiplies every gradient on load (loss-scale / accumulation mean; 1 = none). */
+typedef struct AcaiAdamWTensor {
+    float *p;
+    const float *g;
+    float *m, *v;
+    int64_t n;
+    int32_t group, pad_;
+} AcaiAdamWTensor;
+typedef struct AcaiAdamWGroup {
+    float lr, beta1, beta2, eps, weight_decay, bias_c1, bias_c2_sqrt, pad_;
+} AcaiAdamWGroup;
+int acai_adamw_step(const AcaiAdamWTensor *tensors, const AcaiAdamWGroup *groups, const int32_t *chunk_tensor, const int64_t *chunk_off,
+                    int n_chunks, int chunk_elems, float grad_scale, void *stream);
+
 /* ---- KV-cached greedy decode (K:190-223, K:292-302, M:518-528, M:575-583) ------------------------------- */
 typedef struct {
     const void *self_in_w;   const float *self_in_b;   /* self_attn.in_proj_{weight,bias} [3E,E] */
