@@ -84,6 +84,11 @@ struct TileLayout {
 // exact-erf GELU, as torch's F.gelu(approximate="none")
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// d/dx of the exact-erf GELU
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+
 template <typename T> struct DT;
 template <> struct DT<float> {
     static constexpr int id = ACAI_F32;

@@ -25,6 +25,10 @@ struct GemmArgs {
     int lda, ldw, ldr, ldc, M, N, K, out_dtype, flags;
     int vec_epi; // host-checked: C (and the residual) allow 16-byte row accesses -> LDS-transposed epilogue
     int ksplit;  // > 0: split-K over `ksplit` workgroups per tile, fp32 atomic accumulation into C (weight gradients: K = rows)
+    // aux_mode 1: `aux` (dtype of C) also receives the pre-activation while C gets GELU of it (training forward keeps both);
+    // aux_mode 2: C = round(acc) * gelu'(aux)  (the dX GEMM of linear2 applies the GELU derivative of the saved pre-activation)
+    void *aux;
+    int ldaux, aux_mode;
     // EPI == 1 (cross K/V prefill scatter)
     const int32_t *row_seq, *row_pos, *seq_len;
     const int64_t *seq_off;
@@ -82,6 +86,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&
                 }
                 if constexpr (EPI == 0) {
                     if (do_round) v = round_bf16(v);
+                    if (g.aux_mode == 1) {
+                        if (g.out_dtype == ACAI_BF16) reinterpret_cast<bf16_t *>(g.aux)[(size_t)row * g.ldaux + col] = f2bf(v);
+                        else reinterpret_cast<float *>(g.aux)[(size_t)row * g.ldaux + col] = v;
+                    } else if (g.aux_mode == 2) {
+                        const float a0 = g.out_dtype == ACAI_BF16 ? bf2f(reinterpret_cast<const bf16_t *>(g.aux)[(size_t)row * g.ldaux + col])
+                                                                  : reinterpret_cast<const float *>(g.aux)[(size_t)row * g.ldaux + col];
+                        v *= gelu_erf_grad(a0);
+                    }
                     if (do_gelu) {
                         v = gelu_erf(v);
                         if (do_round) v = round_bf16(v);
@@ -264,6 +276,93 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     gemm_epilogue<EPI, TA && TB>(g, acc, bm0, bn0, wm, wn, lr, lh);
 }
 
+// ---- LDS-transposed epilogue of the LDS-DMA kernels -----------------------------------------------------------------------------------
+// The MFMA C/D layout gives a lane one column and 16 scattered rows: storing from it means 2- or 4-byte stores in 64/128-byte runs, which
+// bounds the short-K GEMMs (K = 512..768: 8-12 K-steps per output tile).  Each wave therefore transposes its 64x64 block through `stg`
+// (its share of the now free LDS stages), 32 rows at a time, and writes 16 bytes per lane along the rows.  Bias and bf16 rounding are applied
+// on the way in; GELU (optionally keeping the pre-activation in `aux`), the GELU-derivative product and the fp32 residual on the way out.
+__device__ __forceinline__ void gemm_vec_epilogue(const GemmArgs &g, const f32x16 (&acc)[2][2], float *stg, int bm0, int bn0, int wm, int wn, int lane) {
+    constexpr int EP = 68;  // floats per staged row (64 + 4: 16-byte aligned rows, conflict-light)
+    const int lr = lane & 31, lh = lane >> 5;
+    const int ldc_e = g.ldc, n_valid = g.N - (bn0 + wn * 64);
+    const bool do_gelu = g.flags & ACAI_GEMM_GELU, do_round = g.flags & ACAI_GEMM_ROUND_BF16;
+    auto finish = [&](f32x4 &v, int row, int col) {   // four consecutive columns of one row, after bias / rounding
+        if (g.aux_mode == 2) {
+            float a4[4];
+            if (g.out_dtype == ACAI_BF16) {
+                const uint2 r = *reinterpret_cast<const uint2 *>(reinterpret_cast<const bf16_t *>(g.aux) + (size_t)row * g.ldaux + col);
+                a4[0] = __uint_as_float(r.x << 16); a4[1] = __uint_as_float(r.x & 0xFFFF0000u);
+                a4[2] = __uint_as_float(r.y << 16); a4[3] = __uint_as_float(r.y & 0xFFFF0000u);
+            } else {
+                const f32x4 r = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(g.aux) + (size_t)row * g.ldaux + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a4[e] = r[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(a4[e]);
+        }
+        if (g.aux_mode == 1) {
+            if (g.out_dtype == ACAI_BF16) {
+                uint2 o;
+                o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]);
+                *reinterpret_cast<uint2 *>(reinterpret_cast<bf16_t *>(g.aux) + (size_t)row * g.ldaux + col) = o;
+            } else {
+                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.aux) + (size_t)row * g.ldaux + col) = v;
+            }
+        }
+        if (do_gelu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = gelu_erf(v[e]);
+                if (do_round) v[e] = round_bf16(v[e]);
+            }
+        }
+        if (g.residual) v += *reinterpret_cast<const f32x4 *>(g.residual + (size_t)row * g.ldr + col);
+    };
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = bn0 + wn * 64 + j * 32 + lr;
+            const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[i][j][e] + bv;
+                if (do_round) v = round_bf16(v);
+                stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * EP + j * 32 + lr] = v;
+            }
+        }
+        // same wave wrote and now reads: LDS operations of a wave complete in order
+        const int row_base = bm0 + wm * 64 + i * 32, col_base = bn0 + wn * 64;
+        if (g.out_dtype == ACAI_BF16) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = it * 64 + lane, r = idx >> 3, c8 = (idx & 7) * 8;
+                const int row = row_base + r;
+                if (row < g.M && c8 < n_valid) {
+                    f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c8), v1 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c8 + 4);
+                    finish(v0, row, col_base + c8);
+                    finish(v1, row, col_base + c8 + 4);
+                    uint4 o;
+                    o.x = pack_bf16(v0[0], v0[1]); o.y = pack_bf16(v0[2], v0[3]); o.z = pack_bf16(v1[0], v1[1]); o.w = pack_bf16(v1[2], v1[3]);
+                    *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(g.C) + (size_t)row * ldc_e + col_base + c8) = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = it * 64 + lane, r = idx >> 4, c4 = (idx & 15) * 4;
+                const int row = row_base + r;
+                if (row < g.M && c4 < n_valid) {
+                    f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c4);
+                    finish(v0, row, col_base + c4);
+                    *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)row * ldc_e + col_base + c4) = v0;
+                }
+            }
+        }
+    }
+}
+
 // ---- NT main loop with direct-to-LDS staging (global_load_lds, 16 B per lane) ------------------------------------------------
 // For row-major operands with K % BK == 0: no staging VGPRs, two LDS stages (64 KB), tile t+1 in flight while tile t feeds the MFMAs,
 // one barrier per K-step.  An LDS-DMA wave instruction writes 1 KiB linearly (lane l -> base + 16 l = row l/8, slot l%8 of an unpadded
@@ -376,70 +475,14 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2))) v
         compute(lds0);
         __syncthreads();
     }
-    // ---- epilogue ---------------------------------------------------------------------------------------------------------
-    // The MFMA C/D layout gives a lane one column and 16 scattered rows: storing from it means 2- or 4-byte stores in 64/128-byte
-    // runs, which bounds the short-K GEMMs (K = 512..768: 8-12 K-steps per 128x128 output tile).  Each wave therefore transposes its
-    // 64x64 block through its own 16 KB of the (now free) LDS, 32 rows at a time, and writes 16 bytes per lane along the rows; bias /
-    // bf16 rounding / GELU are applied on the way in, the fp32 residual on the way out.
-    constexpr int EP = 68;  // floats per staged row (64 + 4: 16-byte aligned rows, conflict-light)
-    const int ldc_e = g.ldc, n_valid = g.N - (bn0 + wn * 64);
+    // ---- epilogue (see gemm_vec_epilogue) ------------------------------------------------------------------------------------------------
     if (EPI != 0 || !g.vec_epi) {
         gemm_epilogue<EPI, false>(g, acc, bm0, bn0, wm, wn, lr, lh);
         return;
     }
     // every wave is past the last barrier: both stages are free; a wave stages 32 rows x 68 floats = 8.5 KB
     float *stg = reinterpret_cast<float *>((wave < WM ? lds0 : lds1) + (wave % WM) * (STAGE / WM));
-    const bool do_gelu = g.flags & ACAI_GEMM_GELU, do_round = g.flags & ACAI_GEMM_ROUND_BF16;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = bn0 + wn * 64 + j * 32 + lr;
-            const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = acc[i][j][e] + bv;
-                if (do_round) v = round_bf16(v);
-                if (do_gelu) {
-                    v = gelu_erf(v);
-                    if (do_round) v = round_bf16(v);
-                }
-                stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * EP + j * 32 + lr] = v;
-            }
-        }
-        // same wave wrote and now reads: LDS operations of a wave complete in order
-        const int row_base = bm0 + wm * 64 + i * 32, col_base = bn0 + wn * 64;
-        if (g.out_dtype == ACAI_BF16) {
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int idx = it * 64 + lane, r = idx >> 3, c8 = (idx & 7) * 8;
-                const int row = row_base + r;
-                if (row < g.M && c8 < n_valid) {
-                    f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c8), v1 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c8 + 4);
-                    if (g.residual) {
-                        const float *rp = g.residual + (size_t)row * g.ldr + col_base + c8;
-                        const f32x4 r0 = *reinterpret_cast<const f32x4 *>(rp), r1 = *reinterpret_cast<const f32x4 *>(rp + 4);
-                        v0 += r0;
-                        v1 += r1;
-                    }
-                    uint4 o;
-                    o.x = pack_bf16(v0[0], v0[1]); o.y = pack_bf16(v0[2], v0[3]); o.z = pack_bf16(v1[0], v1[1]); o.w = pack_bf16(v1[2], v1[3]);
-                    *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(g.C) + (size_t)row * ldc_e + col_base + c8) = o;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int idx = it * 64 + lane, r = idx >> 4, c4 = (idx & 15) * 4;
-                const int row = row_base + r;
-                if (row < g.M && c4 < n_valid) {
-                    f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c4);
-                    if (g.residual) v0 += *reinterpret_cast<const f32x4 *>(g.residual + (size_t)row * g.ldr + col_base + c4);
-                    *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)row * ldc_e + col_base + c4) = v0;
-                }
-            }
-        }
-    }
+    gemm_vec_epilogue(g, acc, stg, bm0, bn0, wm, wn, lane);
 }
 
 // ---- 256x128 tile, 8 waves, THREE LDS stages (144 KB): two K-tiles in flight ------------------------------------------------------------
@@ -567,70 +610,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
         if (kt + 2 < nkt) step(kt + 2, lds2, lds1);
     }
     __syncthreads();  // all tiles consumed, nothing in flight: the stages become the epilogue's staging space
-    // ---- epilogue ---------------------------------------------------------------------------------------------------------
-    // The MFMA C/D layout gives a lane one column and 16 scattered rows: storing from it means 2- or 4-byte stores in 64/128-byte
-    // runs, which bounds the short-K GEMMs (K = 512..768: 8-12 K-steps per 128x128 output tile).  Each wave therefore transposes its
-    // 64x64 block through its own 16 KB of the (now free) LDS, 32 rows at a time, and writes 16 bytes per lane along the rows; bias /
-    // bf16 rounding / GELU are applied on the way in, the fp32 residual on the way out.
-    constexpr int EP = 68;  // floats per staged row (64 + 4: 16-byte aligned rows, conflict-light)
-    const int ldc_e = g.ldc, n_valid = g.N - (bn0 + wn * 64);
+    // ---- epilogue (see gemm_vec_epilogue) ------------------------------------------------------------------------------------------------
     if (EPI != 0 || !g.vec_epi) {
         gemm_epilogue<EPI, false>(g, acc, bm0, bn0, wm, wn, lr, lh);
         return;
     }
     // every wave is past the last barrier: both stages are free; a wave stages 32 rows x 68 floats = 8.5 KB
     float *stg = reinterpret_cast<float *>((wave < WM ? lds0 : lds1) + (wave % WM) * (STAGE / WM));
-    const bool do_gelu = g.flags & ACAI_GEMM_GELU, do_round = g.flags & ACAI_GEMM_ROUND_BF16;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = bn0 + wn * 64 + j * 32 + lr;
-            const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = acc[i][j][e] + bv;
-                if (do_round) v = round_bf16(v);
-                if (do_gelu) {
-                    v = gelu_erf(v);
-                    if (do_round) v = round_bf16(v);
-                }
-                stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * EP + j * 32 + lr] = v;
-            }
-        }
-        // same wave wrote and now reads: LDS operations of a wave complete in order
-        const int row_base = bm0 + wm * 64 + i * 32, col_base = bn0 + wn * 64;
-        if (g.out_dtype == ACAI_BF16) {
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int idx = it * 64 + lane, r = idx >> 3, c8 = (idx & 7) * 8;
-                const int row = row_base + r;
-                if (row < g.M && c8 < n_valid) {
-                    f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c8), v1 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c8 + 4);
-                    if (g.residual) {
-                        const float *rp = g.residual + (size_t)row * g.ldr + col_base + c8;
-                        const f32x4 r0 = *reinterpret_cast<const f32x4 *>(rp), r1 = *reinterpret_cast<const f32x4 *>(rp + 4);
-                        v0 += r0;
-                        v1 += r1;
-                    }
-                    uint4 o;
-                    o.x = pack_bf16(v0[0], v0[1]); o.y = pack_bf16(v0[2], v0[3]); o.z = pack_bf16(v1[0], v1[1]); o.w = pack_bf16(v1[2], v1[3]);
-                    *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(g.C) + (size_t)row * ldc_e + col_base + c8) = o;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int idx = it * 64 + lane, r = idx >> 4, c4 = (idx & 15) * 4;
-                const int row = row_base + r;
-                if (row < g.M && c4 < n_valid) {
-                    f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c4);
-                    if (g.residual) v0 += *reinterpret_cast<const f32x4 *>(g.residual + (size_t)row * g.ldr + col_base + c4);
-                    *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)row * ldc_e + col_base + c4) = v0;
-                }
-            }
-        }
-    }
+    gemm_vec_epilogue(g, acc, stg, bm0, bn0, wm, wn, lane);
 }
 
 template <typename T, int EPI, bool TA = false, bool TB = false>
@@ -650,7 +637,8 @@ int launch(const GemmArgs &g, hipStream_t st) {
         h.ksplit = ks;
         nwg *= ks;
     }
-    h.vec_epi = (EPI == 0) && (g.ldc % 8 == 0) && (g.N % 8 == 0) && aligned16(g.C) && (!g.residual || (g.ldr % 4 == 0 && aligned16(g.residual)));
+    h.vec_epi = (EPI == 0) && (g.ldc % 8 == 0) && (g.N % 8 == 0) && aligned16(g.C) && (!g.residual || (g.ldr % 4 == 0 && aligned16(g.residual))) &&
+                (!g.aux_mode || (g.ldaux % 8 == 0 && aligned16(g.aux)));
     constexpr int BKG = ROWB / (int)sizeof(T);
     static const bool no_glds = getenv("ACAI_GEMM_NO_GLDS") != nullptr;
     static const char *force_wm = getenv("ACAI_GEMM_WM");   // A/B aid: "2" or "4"
@@ -675,19 +663,29 @@ int launch(const GemmArgs &g, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int acai_gemm_nt(const void *A, int lda, const void *W, int ldw, const float *bias, const float *residual, int ldr,
-                            void *C, int ldc, int M, int N, int K, int in_dtype, int out_dtype, int flags, void *stream) {
+extern "C" int acai_gemm_nt_ex(const void *A, int lda, const void *W, int ldw, const float *bias, const float *residual, int ldr,
+                               void *C, int ldc, void *aux, int ldaux, int aux_mode, int M, int N, int K, int in_dtype, int out_dtype, int flags,
+                               void *stream) {
     ACAI_CHECK_ARG(A && W && C, "acai_gemm_nt: null operand");
     ACAI_CHECK_ARG(M >= 0 && N > 0 && K > 0, "acai_gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
     ACAI_CHECK_ARG(lda >= K && ldw >= K && ldc >= N && (!residual || ldr >= N), "acai_gemm_nt: leading dimension smaller than row");
     ACAI_CHECK_ARG((in_dtype == ACAI_F32 || in_dtype == ACAI_BF16) && (out_dtype == ACAI_F32 || out_dtype == ACAI_BF16),
                    "acai_gemm_nt: bad dtype");
+    ACAI_CHECK_ARG(aux_mode >= 0 && aux_mode <= 2 && (aux_mode == 0 || (aux && ldaux >= N)), "acai_gemm_nt_ex: bad aux operand (mode %d)", aux_mode);
+    ACAI_CHECK_ARG(aux_mode != 1 || (flags & ACAI_GEMM_GELU), "acai_gemm_nt_ex: aux_mode 1 keeps the pre-activation of a GELU epilogue");
+    ACAI_CHECK_ARG(aux_mode != 2 || !(flags & ACAI_GEMM_GELU), "acai_gemm_nt_ex: aux_mode 2 (GELU derivative) excludes the GELU flag");
     if (M == 0) return 0;
     GemmArgs g{};
     g.A = A; g.W = W; g.bias = bias; g.residual = residual; g.C = C;
     g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.out_dtype = out_dtype; g.flags = flags;
+    g.aux = aux; g.ldaux = ldaux; g.aux_mode = aux_mode;
     return in_dtype == ACAI_BF16 ? launch<bf16_t, 0>(g, (hipStream_t)stream) : launch<float, 0>(g, (hipStream_t)stream);
+}
+
+extern "C" int acai_gemm_nt(const void *A, int lda, const void *W, int ldw, const float *bias, const float *residual, int ldr,
+                            void *C, int ldc, int M, int N, int K, int in_dtype, int out_dtype, int flags, void *stream) {
+    return acai_gemm_nt_ex(A, lda, W, ldw, bias, residual, ldr, C, ldc, nullptr, 0, 0, M, N, K, in_dtype, out_dtype, flags, stream);
 }
 
 // General form for the backward pass: C[M,N] = op(A) . op(W)^T (+bias) (+residual), logical A [M,K], logical W [N,K];

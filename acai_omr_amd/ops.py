@@ -53,8 +53,10 @@ def layernorm(x, w, b, eps, want_f32=True, want_bf16=False, out_f32=None):
     return y32, y16
 
 
-def gemm_nt(a, w, bias=None, residual=None, out_dtype=torch.float32, gelu=False, round_bf16=False, out=None):
-    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias) (+ residual).  a, w share a dtype (fp32 or bf16); 2-D, row stride free."""
+def gemm_nt(a, w, bias=None, residual=None, out_dtype=torch.float32, gelu=False, round_bf16=False, out=None, pre_act=None, gelu_grad_of=None):
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias) (+ residual).  a, w share a dtype (fp32 or bf16); 2-D, row stride free.
+    pre_act (with gelu): [M,N] tensor of out's dtype that receives the pre-activation; gelu_grad_of: [M,N] saved pre-activation whose GELU
+    derivative multiplies the (rounded) product."""
     _chk(a, "a"), _chk(w, "w")
     assert a.dim() == 2 and w.dim() == 2 and a.dtype == w.dtype and a.shape[1] == w.shape[1], (a.shape, w.shape, a.dtype, w.dtype)
     M, K = a.shape
@@ -67,6 +69,14 @@ def gemm_nt(a, w, bias=None, residual=None, out_dtype=torch.float32, gelu=False,
     if residual is not None:
         assert residual.dtype == torch.float32 and residual.shape == (M, N) and residual.stride(1) == 1
     flags = (GEMM_GELU if gelu else 0) | (GEMM_ROUND_BF16 if round_bf16 else 0)
+    aux = pre_act if pre_act is not None else gelu_grad_of
+    if aux is not None:
+        assert (pre_act is None) != (gelu_grad_of is None) and aux.shape == (M, N) and aux.dtype == out.dtype and aux.stride(1) == 1
+        assert (pre_act is None) or gelu
+        _lib.check(_lib.lib().acai_gemm_nt_ex(a.data_ptr(), _ld(a), w.data_ptr(), _ld(w), _p(bias), _p(residual),
+                                              _ld(residual) if residual is not None else 0, out.data_ptr(), _ld(out), aux.data_ptr(), _ld(aux),
+                                              1 if pre_act is not None else 2, M, N, K, _dt(a), _dt(out), flags, _st()), "acai_gemm_nt_ex")
+        return out
     _lib.check(_lib.lib().acai_gemm_nt(a.data_ptr(), _ld(a), w.data_ptr(), _ld(w), _p(bias), _p(residual),
                                        _ld(residual) if residual is not None else 0, out.data_ptr(), _ld(out),
                                        M, N, K, _dt(a), _dt(out), flags, _st()), "acai_gemm_nt")

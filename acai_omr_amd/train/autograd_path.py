@@ -11,6 +11,8 @@ Step semantics reproduced: MAE pre-training runs fp32
 the inference path.  Dropout (train mode) is a counter-based hash mask regenerated in backward: residual dropouts through
 `acai_dropout_add`, attention-probability dropout inside the flash kernels; seeds come from torch's CPU generator.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -54,6 +56,22 @@ def _side_put(t, tb):
     _SIDE[:] = [(t, tb)]
 
 
+_FWD_SIDE = []   # forward twin: bf16 copy of a LayerNorm output, consumed by the cast in front of the next bf16 GEMM
+
+
+def _fwd_put(t, tb):
+    _FWD_SIDE[:] = [(t, tb)]
+
+
+def _fwd_take(t):
+    e = _FWD_SIDE.pop() if _FWD_SIDE else None
+    if e is not None and e[0] is t:
+        SIDE_HITS[0] += 1
+        return e[1]
+    SIDE_HITS[1] += 1
+    return None
+
+
 def _side_take(t):
     e = _SIDE.pop() if _SIDE else None
     if e is not None and e[0] is t:
@@ -94,6 +112,57 @@ class LinearFn(Function):
         dW = ops.gemm(dyc, x, trans_a=True, trans_w=True, out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
         db = ops.colsum(dyc) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dW, db, dres, None, None, None
+
+
+class MlpFn(Function):
+    """y = residual + linear2(GELU(linear1(x))) as ONE autograd node (no inner dropout).  The forward GEMM of linear1 writes the pre-activation
+    and its GELU in one epilogue; the backward dX GEMM of linear2 multiplies by the GELU derivative in its epilogue - the stand-alone GELU
+    passes (read + write of the (M, mlp_dim) tensor, twice) disappear."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, residual, prec, wc):
+        bf = prec == "bf16"
+        cdt = torch.bfloat16 if bf else torch.float32
+        a = torch.empty(x.shape[0], W1.shape[0], dtype=cdt, device=x.device)
+        h = ops.gemm_nt(x, wc.w(W1, prec), wc.b(b1, prec), out_dtype=cdt, gelu=True, round_bf16=bf, pre_act=a)
+        y = ops.gemm_nt(h, wc.w(W2, prec), wc.b(b2, prec), residual=residual, out_dtype=torch.float32, round_bf16=bf)
+        ctx.save_for_backward(x, a, h, W1, W2)
+        ctx.prec, ctx.wc = prec, wc
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a, h, W1, W2 = ctx.saved_tensors
+        prec, wc, bf = ctx.prec, ctx.wc, ctx.prec == "bf16"
+        dy = dy.contiguous()
+        dyc = dy
+        if bf and dy.dtype != torch.bfloat16:
+            dyc = _side_take(dy)
+            if dyc is None:
+                dyc = ops.cast_bf16(dy)
+        elif not bf and dy.dtype != torch.float32:
+            dyc = dy.float()
+        da = ops.gemm_nt(dyc, wc.wt(W2, prec), out_dtype=a.dtype, round_bf16=bf, gelu_grad_of=a)     # (dY . W2) o gelu'(a)
+        dW2 = ops.gemm(dyc, h, trans_a=True, trans_w=True, out_dtype=torch.float32) if ctx.needs_input_grad[3] else None
+        db2 = ops.colsum(dyc) if ctx.needs_input_grad[4] else None
+        dx = ops.gemm_nt(da, wc.wt(W1, prec), out_dtype=x.dtype) if ctx.needs_input_grad[0] else None
+        dW1 = ops.gemm(da, x, trans_a=True, trans_w=True, out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        db1 = ops.colsum(da) if ctx.needs_input_grad[2] else None
+        return dx, dW1, db1, dW2, db2, dy, None, None
+
+
+_FUSED_MLP = os.environ.get("ACAI_FUSED_MLP", "1") != "0"   # A/B aid
+
+
+def _mlp(xc, x32, lin1, lin2, p_inner, p_out, prec, wc):
+    """linear1 -> GELU -> (dropout) -> linear2 -> (dropout) + residual x32; xc = x32 in the compute dtype."""
+    if _FUSED_MLP and p_inner <= 0.0 and p_out <= 0.0 and lin1.bias is not None and lin2.bias is not None:
+        return MlpFn.apply(xc, lin1.weight, lin1.bias, lin2.weight, lin2.bias, x32, prec, wc)
+    a = LinearFn.apply(xc, lin1.weight, lin1.bias, None, prec, wc, False)
+    h = GeluFn.apply(a)
+    if p_inner > 0:
+        h = DropoutAddFn.apply(h, None, p_inner, _next_seed())
+    return _proj_residual(h, lin2.weight, lin2.bias, x32, p_out, prec, wc)
 
 
 class SelfAttnFn(Function):
@@ -173,10 +242,13 @@ def _proj_residual(x, lin_w, lin_b, residual, p, prec, wc):
 class LayerNormFn(Function):
     @staticmethod
     def forward(ctx, x, w, b, eps):
-        y = ops.layernorm(x, w.detach(), b.detach(), eps)[0]
+        bf = _prec() == "bf16"
+        y, yb = ops.layernorm(x, w.detach(), b.detach(), eps, want_bf16=bf)
+        if bf:
+            _fwd_put(y, yb)   # the next bf16 GEMM reads this copy instead of casting y again
         ctx.save_for_backward(x, w)
         ctx.eps = eps
-        ctx.bf = _prec() == "bf16" and x.shape[1] % 256 == 0 and x.shape[1] <= 1024   # the consumer of dx is a bf16 GEMM
+        ctx.bf = bf and x.shape[1] % 256 == 0 and x.shape[1] <= 1024   # the consumer of dx is a bf16 GEMM
         return y
 
     @staticmethod
@@ -193,7 +265,8 @@ class LayerNormFn(Function):
 class CastBf16Fn(Function):
     @staticmethod
     def forward(ctx, x):
-        return ops.cast_bf16(x)
+        xb = _fwd_take(x)
+        return xb if xb is not None else ops.cast_bf16(x)
 
     @staticmethod
     def backward(ctx, dy):
@@ -274,11 +347,8 @@ def encoder_stack(stack, x32, cu, max_len, H, prec, wc, training=False):
         attn = SelfAttnFn.apply(qkv, cu, H, dh, max_len, False, _p_of(sa, training))
         y = _proj_residual(attn, sa.out_proj.weight, sa.out_proj.bias, x32, _p_of(layer.dropout1, training), prec, wc)
         x32 = LayerNormFn.apply(y, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
-        a = _lin(x32, layer.linear1.weight, layer.linear1.bias, prec, wc)
-        h = GeluFn.apply(a)
-        if _p_of(layer.dropout, training) > 0:
-            h = DropoutAddFn.apply(h, None, _p_of(layer.dropout, training), _next_seed())
-        y = _proj_residual(h, layer.linear2.weight, layer.linear2.bias, x32, _p_of(layer.dropout2, training), prec, wc)
+        xc = CastBf16Fn.apply(x32) if prec == "bf16" else x32
+        y = _mlp(xc, x32, layer.linear1, layer.linear2, _p_of(layer.dropout, training), _p_of(layer.dropout2, training), prec, wc)
         x32 = LayerNormFn.apply(y, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
     if stack.norm is not None:
         x32 = LayerNormFn.apply(x32, stack.norm.weight, stack.norm.bias, stack.norm.eps)
@@ -527,11 +597,8 @@ def decoder_forward(dec, input_seqs, img_latent, lmx_attention_mask, latent_atte
         a = CrossAttnFn.apply(q, kv, cu_t, cu_s, H, dh, mt, ms, _p_of(ca, tr))
         y = _proj_residual(a, ca.out_proj.weight, ca.out_proj.bias, x32, _p_of(ly.dropout2, tr), prec, wc)
         x32 = LayerNormFn.apply(y, ly.norm2.weight, ly.norm2.bias, ly.norm2.eps)
-        a1 = _lin(x32, ly.linear1.weight, ly.linear1.bias, prec, wc)
-        h = GeluFn.apply(a1)
-        if _p_of(ly.dropout, tr) > 0:
-            h = DropoutAddFn.apply(h, None, _p_of(ly.dropout, tr), _next_seed())
-        y = _proj_residual(h, ly.linear2.weight, ly.linear2.bias, x32, _p_of(ly.dropout3, tr), prec, wc)
+        xc = CastBf16Fn.apply(x32) if prec == "bf16" else x32
+        y = _mlp(xc, x32, ly.linear1, ly.linear2, _p_of(ly.dropout, tr), _p_of(ly.dropout3, tr), prec, wc)
         x32 = LayerNormFn.apply(y, ly.norm3.weight, ly.norm3.bias, ly.norm3.eps)
     nrm = dec.decoder_blocks.norm
     x32 = LayerNormFn.apply(x32, nrm.weight, nrm.bias, nrm.eps)

@@ -44,6 +44,13 @@ int acai_layernorm_fwd(const float *x, const float *w, const float *b, float eps
  * C has `out_dtype`; bias and residual are fp32 (NULL = absent). */
 int acai_gemm_nt(const void *A, int lda, const void *W, int ldw, const float *bias, const float *residual, int ldr,
                  void *C, int ldc, int M, int N, int K, int in_dtype, int out_dtype, int flags, void *stream);
+/* acai_gemm_nt with an auxiliary [M][N] operand of C's dtype (the MLP of nn.TransformerEncoderLayer / DecoderLayer in training:
+ * linear1 -> GELU -> linear2, acai_omr/models/models.py:30-34,186-190,422-426 and their autograd):
+ *   aux_mode 1 (with ACAI_GEMM_GELU): aux receives the pre-activation (bias added, bf16-rounded if asked), C its GELU - the forward keeps both;
+ *   aux_mode 2: C = round(A.W^T) * gelu'(aux) - the dX GEMM of linear2 multiplies by the GELU derivative of the saved pre-activation. */
+int acai_gemm_nt_ex(const void *A, int lda, const void *W, int ldw, const float *bias, const float *residual, int ldr,
+                    void *C, int ldc, void *aux, int ldaux, int aux_mode, int M, int N, int K, int in_dtype, int out_dtype, int flags,
+                    void *stream);
 
 /* The same contraction with either operand stored reduction-major, for the backward of nn.Linear (autograd of M:29,57,...):
  *   dX = dY . W   -> acai_gemm(dY, ldy, 0,  W, ldw, 1, ...)  (M = rows, N = in_features, K = out_features)

@@ -199,3 +199,29 @@ def test_decode_attn(dev, H, dh, lens, dtype, fused_merge):
             s = (q[b, h * dh:(h + 1) * dh].double() @ ks[b][h].double().t()) / math.sqrt(dh)
             ref = torch.softmax(s, -1) @ vs[b][h].double()
             assert (out[b, h * dh:(h + 1) * dh].cpu().double() - ref).abs().max() < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("shape", [(300, 136, 64), (16384 + 8, 2048, 128)])
+def test_gemm_nt_gelu_aux_modes(dev, dtype, shape):
+    """acai_gemm_nt_ex: aux_mode 1 keeps the pre-activation next to its GELU; aux_mode 2 multiplies the product by gelu'(aux) - checked
+    against the unfused kernels (gemm + gelu_fwd / gelu_bwd), which they replace in the training MLP."""
+    from acai_omr_amd import ops
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N)
+    dt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    a = torch.randn(M, K, generator=g).to(dev).to(dt)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev).to(dt)
+    b = torch.randn(N, generator=g).to(dev)
+    rnd = dtype == "bf16"
+    pre = torch.empty(M, N, dtype=dt, device=dev)
+    h = ops.gemm_nt(a, w, b, out_dtype=dt, gelu=True, round_bf16=rnd, pre_act=pre)
+    pre_ref = ops.gemm_nt(a, w, b, out_dtype=dt, round_bf16=rnd)
+    assert torch.equal(pre, pre_ref)
+    assert torch.equal(h, ops.gelu_fwd(pre_ref))
+    # derivative epilogue: (a . w^T) o gelu'(saved)
+    saved = torch.randn(M, N, generator=g).to(dev).to(dt)
+    fused = ops.gemm_nt(a, w, out_dtype=dt, round_bf16=rnd, gelu_grad_of=saved)
+    ref = ops.gelu_bwd(saved, ops.gemm_nt(a, w, out_dtype=dt, round_bf16=rnd))
+    assert torch.equal(fused, ref) if dtype == "bf16" else torch.allclose(fused, ref, rtol=1e-6, atol=1e-7)
