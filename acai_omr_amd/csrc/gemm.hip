@@ -78,12 +78,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&
                 const int row = bm0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 if (row >= g.M) continue;
                 float v = acc[i][j][e] + bv;
-                if constexpr (EPI == 0 && TA && TB) {
-                    if (g.ksplit > 0) {  // weight gradient: accumulate (C is fp32 and was zeroed or holds a running gradient)
-                        atomicAdd(reinterpret_cast<float *>(g.C) + (size_t)row * g.ldc + col, v);
-                        continue;
-                    }
-                }
                 if constexpr (EPI == 0) {
                     if (do_round) v = round_bf16(v);
                     if (g.aux_mode == 1) {
@@ -114,6 +108,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&
                 }
             }
     }
+}
+
+// Split-K accumulation epilogue (weight gradients): fp32 atomics straight from the C/D layout - a wave instruction adds two 128-byte row
+// segments, the shape the atomic units take at full rate.  One 32x32 block at a time behind a scheduling barrier: left to itself the compiler
+// materialises all 64 row addresses first, which cost the register-staged dW kernel 430 registers (one wave per SIMD).
+__device__ __forceinline__ void gemm_accum_epilogue(const GemmArgs &g, const f32x16 (&acc)[2][2], int bm0, int bn0, int wm, int wn, int lr, int lh) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = bn0 + wn * 64 + j * 32 + lr, row0 = bm0 + wm * 64 + i * 32 + 4 * lh;
+            if (col < g.N) {
+                float *base = reinterpret_cast<float *>(g.C) + (size_t)row0 * g.ldc + col;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ro = (e & 3) + 8 * (e >> 2);
+                    if (row0 + ro < g.M) atomicAdd(base + (size_t)ro * g.ldc, acc[i][j][e]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 }
 
 // Transposed storage (backward GEMMs: dX = dY.W reads W as [K][N]; dW = dY^T.X reads both operands reduction-major):
@@ -273,6 +288,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
         }
     }
 
+    if constexpr (EPI == 0 && TA && TB) {
+        if (g.ksplit > 0) {
+            gemm_accum_epilogue(g, acc, bm0, bn0, wm, wn, lr, lh);
+            return;
+        }
+    }
     gemm_epilogue<EPI, TA && TB>(g, acc, bm0, bn0, wm, wn, lr, lh);
 }
 
@@ -620,6 +641,111 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     gemm_vec_epilogue(g, acc, stg, bm0, bn0, wm, wn, lane);
 }
 
+// ---- dW = dY^T . X with direct-to-LDS staging (bf16) ----------------------------------------------------------------------------------
+// Both operands are stored contraction-major ([Kc][M] and [Kc][N], Kc = tokens): a K-step stages 64 token rows x 128 columns of each in its
+// natural image (256-byte rows, four rows per 1 KiB LDS-DMA instruction) and the MFMA fragments - eight consecutive tokens of one column -
+// come from ds_read_b64_tr_b16.  A transposing read covers 4 token rows x 64 bytes per 32 lanes; with 256-byte rows those four rows share
+// their banks, so the 64-byte block index is XORed with (token row & 3) on both sides (DMA source address / fragment address).  Two LDS
+// stages as distinct objects, split-K over the tokens with fp32 atomics into the gradient (as the register-staged form it replaces, which
+// ran at ~0.4 PF with one stage and two barriers per K-step).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_tn_glds_kernel(GemmArgs g) {
+    typedef bf16_t T;
+    constexpr int BKT = 64, STAGE = 2 * BKT * 256;  // 32 KB: A image then W image
+    __shared__ __attribute__((aligned(16))) unsigned char lds0[STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char lds1[STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+    const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BM - 1) / BM, nwg = nbn * nbm;
+    int pid = blockIdx.x, kslice = 0;
+    if (g.ksplit > 1) {
+        kslice = pid / nwg;
+        pid -= kslice * nwg;
+    }
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = pid % 8, idx = pid / 8;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm0 = (pid / nbn) * BM, bn0 = (pid % nbn) * BN;
+    int nkt = g.K / BKT, kt_begin = 0;
+    if (g.ksplit > 1) {
+        const int per = (nkt + g.ksplit - 1) / g.ksplit;
+        kt_begin = kslice * per;
+        nkt = min(nkt, kt_begin + per);
+        if (kt_begin >= nkt) return;  // uniform per workgroup, before any barrier
+    }
+    const T *A = reinterpret_cast<const T *>(g.A);
+    const T *W = reinterpret_cast<const T *>(g.W);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // LDS-DMA instruction j = wave * 4 + i covers token rows 4j .. 4j+3 of the stage; lane l lands at row 4j + l/16, 16-byte unit l%16, which
+    // holds logical unit (l%16) ^ ((row & 3) << 2).  Columns beyond M / N are clamped to the last whole chunk (their outputs are never stored).
+    const T *srcA[4], *srcW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 4 + (lane >> 4);
+        const int u = (lane & 15) ^ ((r & 3) << 2);
+        srcA[i] = A + (size_t)r * g.lda + min(bm0 + u * 8, g.M - 8);
+        srcW[i] = W + (size_t)r * g.ldw + min(bn0 + u * 8, g.N - 8);
+    }
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    typedef const __attribute__((address_space(1))) void *glb_ptr;
+    auto issue = [&](int kt, unsigned char *base) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_ptr)(srcA[i] + (size_t)kt * BKT * g.lda), (lds_ptr)(base + (wave * 4 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(srcW[i] + (size_t)kt * BKT * g.ldw), (lds_ptr)(base + BKT * 256 + (wave * 4 + i) * 1024), 16, 0, 0);
+        }
+    };
+    typedef __attribute__((ext_vector_type(4))) short s4;
+    typedef __attribute__((address_space(3))) s4 *lds_s4;
+    const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+    // fragment of output rows rowbase .. rowbase+31, contraction slice s: element j of lane half h is token 16 s + 8 h + j
+    auto frag = [&](const unsigned char *img, int rowbase, int s) -> uint4 {
+        const int m = 16 * s + 8 * lh + (i16 >> 2), bc = (rowbase + 16 * g1 + 4 * (i16 & 3)) * 2;
+        const int o = m * 256 + ((((bc >> 6) ^ (m & 3))) << 6) + (bc & 63);   // rows m and m + 4 share (m & 3)
+        union { s4 v[2]; uint4 u; } r;
+        r.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(img + o));
+        r.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(img + o + 4 * 256));
+        return r.u;
+    };
+    auto compute = [&](const unsigned char *sa) {
+        const unsigned char *sb = sa + BKT * 256;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            uint4 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = frag(sa, wm * 64 + i * 32, s);
+                fb[i] = frag(sb, wn * 64 + i * 32, s);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+        }
+    };
+    issue(kt_begin, lds0);
+    __syncthreads();
+    int kt = kt_begin;
+    for (; kt + 2 <= nkt; kt += 2) {
+        issue(kt + 1, lds1);
+        compute(lds0);
+        __syncthreads();
+        if (kt + 2 < nkt) issue(kt + 2, lds0);
+        compute(lds1);
+        __syncthreads();
+    }
+    if (kt < nkt) compute(lds0);
+    gemm_accum_epilogue(g, acc, bm0, bn0, wm, wn, lr, lh);
+}
+
 template <typename T, int EPI, bool TA = false, bool TB = false>
 int launch(const GemmArgs &g, hipStream_t st) {
     constexpr int EPC = 16 / sizeof(T);
@@ -641,6 +767,14 @@ int launch(const GemmArgs &g, hipStream_t st) {
                 (!g.aux_mode || (g.ldaux % 8 == 0 && aligned16(g.aux)));
     constexpr int BKG = ROWB / (int)sizeof(T);
     static const bool no_glds = getenv("ACAI_GEMM_NO_GLDS") != nullptr;
+    static const bool no_tn = getenv("ACAI_GEMM_NO_TN_GLDS") != nullptr;   // A/B aid
+    if constexpr (TA && TB && EPI == 0 && sizeof(T) == 2) {
+        if (fast && !no_tn && !no_glds && h.ksplit > 0 && g.K % 64 == 0 && g.M % 8 == 0 && g.N % 8 == 0 && g.M >= 8 && g.N >= 8) {
+            hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(nwg), dim3(256), 0, st, h);
+            ACAI_LAUNCH_CHECK("acai_gemm");
+            return 0;
+        }
+    }
     static const char *force_wm = getenv("ACAI_GEMM_WM");   // A/B aid: "2" or "4"
     if (fast && !TA && !TB && g.K % BKG == 0 && !no_glds) {
         const int nwg4 = cdiv(g.M, 256) * cdiv(g.N, BN);

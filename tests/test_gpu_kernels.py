@@ -225,3 +225,30 @@ def test_gemm_nt_gelu_aux_modes(dev, dtype, shape):
     fused = ops.gemm_nt(a, w, out_dtype=dt, round_bf16=rnd, gelu_grad_of=saved)
     ref = ops.gelu_bwd(saved, ops.gemm_nt(a, w, out_dtype=dt, round_bf16=rnd))
     assert torch.equal(fused, ref) if dtype == "bf16" else torch.allclose(fused, ref, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("shape", [(136, 264, 4096), (768, 2304, 8192 + 64), (512, 8, 640), (40, 1000, 192)])
+def test_gemm_weight_gradient_form(dev, dtype, shape):
+    """dW = dY^T X (both operands contraction-major, split-K atomics into an fp32 gradient that may already hold a value): the LDS-DMA
+    transposing-read kernel (bf16, token count % 64 == 0) and the register-staged form (fp32 / other shapes) against fp64."""
+    from acai_omr_amd import ops
+    M, N, K = shape      # dW is [M, N], K = tokens
+    g = torch.Generator().manual_seed(M + N + K)
+    dy, x = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    dt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    if dtype == "bf16":
+        dy, x = rb(dy), rb(x)
+    seed = torch.randn(M, N, generator=g)
+    out = seed.clone().to(dev)
+    ops.gemm(dy.to(dev).to(dt), x.to(dev).to(dt), trans_a=True, trans_w=True, out=out)
+    ref = seed.double() + dy.double().t() @ x.double()
+    tol = 2e-4 * math.sqrt(K)
+    assert (out.cpu().double() - ref).abs().max() < tol, float((out.cpu().double() - ref).abs().max())
+    # column-sliced operands (views into wider buffers), as the fused qkv gradient uses them
+    wide = torch.zeros(K, M + 16, device=dev, dtype=dt)
+    wide[:, 8:8 + M] = dy.to(dev).to(dt)
+    out2 = seed.clone().to(dev)
+    ops.gemm(wide[:, 8:8 + M], x.to(dev).to(dt), trans_a=True, trans_w=True, out=out2)
+    assert (out2.cpu().double() - ref).abs().max() < tol
