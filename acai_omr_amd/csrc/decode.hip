@@ -700,6 +700,92 @@ __global__ __launch_bounds__(256) void argmax_logprob_kernel(const float *logits
     }
 }
 
+// GRPOViTOMR.cached_forward_rollout_policy (M:988-1049), one sampling step: top-k filter, softmax with temperature over the kept logits,
+// draw from that distribution, log-prob of the drawn token under the UN-tempered softmax of the kept logits (the reference takes
+// log_softmax(top_k_logits), M:1017).  torch.multinomial's Philox stream is not reproducible here; the draw is the inverse CDF of a caller
+// supplied uniform u[b][t] over the kept logits in descending order (ties: lower vocabulary index first), so a step is a pure function of
+// (logits, u) that the oracle restates.  One wave per row: k rounds of a wave-wide arg-max build the sorted top-k (k <= 64).
+__global__ __launch_bounds__(256) void sample_logprob_kernel(const float *logits, int V, int B, int64_t *seqs, float *logprobs, int max_len,
+                                                             const int32_t *step, int32_t *finished, int eos, int round_lp,
+                                                             const float *uniforms, int top_k, float inv_temperature) {
+    __shared__ float sv[4][64];
+    __shared__ int si[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const int t = step[0];
+    const float *lg = logits + (size_t)b * V;
+    // lane owns vocabulary entries lane, lane + 64, ... (V <= 512)
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (lane + 64 * j < V) ? lg[lane + 64 * j] : -INFINITY;
+    const int k = min(top_k, V);
+    for (int r = 0; r < k; ++r) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (v[j] > best) {   // ascending j = ascending index: first maximum wins
+                best = v[j];
+                bi = lane + 64 * j;
+            }
+        if (best == -INFINITY) bi = 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > best || (ov == best && oi < bi)) {
+                best = ov;
+                bi = oi;
+            }
+        }
+        if ((bi & 63) == lane) {   // owner removes the winner
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (bi == lane + 64 * j) v[j] = -INFINITY;
+        }
+        if (lane == 0) {
+            sv[wave][r] = best;
+            si[wave][r] = bi;
+        }
+    }
+    // same wave wrote and reads: LDS operations of a wave complete in order
+    const bool in = lane < k;
+    const float x = in ? sv[wave][lane] : -INFINITY, m = sv[wave][0];
+    const float pT = in ? expf((x - m) * inv_temperature) : 0.f;   // softmax(top_k_logits / temperature), unnormalised
+    const float p1 = in ? expf(x - m) : 0.f;                       // softmax(top_k_logits), unnormalised
+    const float sumT = wave_sum(pT), sum1 = wave_sum(p1);
+    float cdf = pT;                                                // inclusive prefix sum over the lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float up = __shfl_up(cdf, o);
+        if (lane >= o) cdf += up;
+    }
+    const float target = uniforms[(size_t)b * max_len + t] * sumT;
+    const unsigned long long hit = __ballot(in && cdf > target);
+    const int r = hit ? __builtin_ctzll(hit) : k - 1;              // rounding at the top of the CDF: last kept entry
+    const int tok = si[wave][r];
+    float lp = (sv[wave][r] - m) - logf(sum1);
+    if (round_lp) lp = round_bf16(lp);
+    if (lane == 0) {
+        seqs[(size_t)b * max_len + t] = tok;
+        logprobs[(size_t)b * max_len + t] = lp;
+        if (tok == eos) finished[b] = 1;
+    }
+}
+
+// loop bookkeeping after a sampling step: unfinished count, advance position and cache length
+__global__ __launch_bounds__(64) void sample_bookkeeping_kernel(int B, int32_t *step, int32_t *finished) {
+    int cnt = 0;
+    for (int b = threadIdx.x; b < B; b += 64) cnt += finished[b] ? 0 : 1;
+    cnt = (int)wave_sum((float)cnt);
+    if (threadIdx.x == 0) {
+        finished[B] = cnt;
+        step[0] = step[0] + 1;
+        step[1] = step[1] + 1;
+    }
+}
+
 __global__ void advance_cache_kernel(int32_t *step) { step[1] = step[1] + 1; }
 
 template <typename TC>
@@ -951,6 +1037,23 @@ extern "C" int acai_decode_step(const AcaiDecoder *d, void *stream) {
     hipLaunchKernelGGL(argmax_logprob_kernel, dim3(1), dim3(256), 0, st, d->logits, d->V, d->B, d->seqs, d->logprobs, d->max_len, d->step,
                        d->finished, d->eos, (d->flags & ACAI_GEMM_ROUND_BF16) ? 1 : 0, 1);
     ACAI_LAUNCH_CHECK("argmax_logprob");
+    return 0;
+}
+
+extern "C" int acai_decode_sample_step(const AcaiDecoder *d, const float *uniforms, int top_k, float temperature, void *stream) {
+    int rc = check_decoder(d);
+    if (rc) return rc;
+    ACAI_CHECK_ARG(d->emb && d->pos && d->unembed_w && d->logits, "acai_decode_sample_step: decoder has no embedding / unembed");
+    ACAI_CHECK_ARG(d->seqs && d->logprobs && d->finished && d->max_len > 1, "acai_decode_sample_step: null sequence state");
+    ACAI_CHECK_ARG(uniforms && top_k >= 1 && top_k <= 64 && temperature > 0.f && d->V <= 512,
+                   "acai_decode_sample_step: needs uniforms, 1 <= top_k <= 64, temperature > 0, vocabulary <= 512 (top_k=%d V=%d)", top_k, d->V);
+    hipStream_t st = (hipStream_t)stream;
+    rc = d->dtype == ACAI_BF16 ? decode_core<bf16_t>(d, nullptr, st) : decode_core<float>(d, nullptr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sample_logprob_kernel, dim3(cdiv(d->B, 4)), dim3(256), 0, st, d->logits, d->V, d->B, d->seqs, d->logprobs, d->max_len, d->step,
+                       d->finished, d->eos, (d->flags & ACAI_GEMM_ROUND_BF16) ? 1 : 0, uniforms, top_k, 1.0f / temperature);
+    hipLaunchKernelGGL(sample_bookkeeping_kernel, dim3(1), dim3(64), 0, st, d->B, d->step, d->finished);
+    ACAI_LAUNCH_CHECK("sample_logprob");
     return 0;
 }
 

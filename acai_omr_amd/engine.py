@@ -184,9 +184,12 @@ class DecodeEngine:
         self._keep = None
 
     # ---- cross K/V prefill (MemoryCache.cache_memory_keys_and_vals, kv_caching.py:235-253) -----------------------------
-    def prepare(self, mem32, memb, lens):
-        """mem32 / memb: packed memory (M, E) fp32 / bf16 copy; lens: per-sequence memory lengths."""
-        B = len(lens)
+    def prepare(self, mem32, memb, lens, group_size=1):
+        """mem32 / memb: packed memory (M, E) fp32 / bf16 copy; lens: per-memory lengths.  group_size > 1: every memory serves `group_size`
+        consecutive decode rows (the rollouts of one image, models.py:883-891) - its cross K/V is projected and stored ONCE and the rows'
+        offsets alias it, instead of the reference's group_size materialised copies."""
+        G = int(group_size)
+        B = len(lens) * G
         if B > self.Bmax:
             raise ValueError(f"The current cache has been setup with a max batch size of {self.Bmax}, but found new key tensors with batch size {B}!")
         E, H, dhp, dev = self.E, self.H, self.dhp, self.device
@@ -200,8 +203,10 @@ class DecodeEngine:
         for l in lens:
             offs.append(o)
             o += l * H * dhp
-        self.cross_off[:B] = torch.tensor(offs, dtype=torch.int64)
-        self.cross_len[:B] = torch.tensor(lens, dtype=torch.int32)
+        self.cross_off[:B] = torch.tensor(offs, dtype=torch.int64).repeat_interleave(G)
+        self.cross_len[:B] = torch.tensor(lens, dtype=torch.int32).repeat_interleave(G)
+        # the prefill scatters by MEMORY index: its own (ungrouped) offset / length tables
+        pre_off, pre_len = torch.tensor(offs, dtype=torch.int64).to(dev), torch.tensor(lens, dtype=torch.int32).to(dev)
         row_seq = torch.cat([torch.full((l,), b, dtype=torch.int32) for b, l in enumerate(lens)]).to(dev)
         row_pos = torch.cat([torch.arange(l, dtype=torch.int32) for l in lens]).to(dev)
         mem = memb if self.bf else mem32
@@ -211,9 +216,9 @@ class DecodeEngine:
             ca = layer.multihead_attn
             w = self.wc.w(ca.in_proj_weight, self.prec)[E:]
             b = self.wc.b(ca.in_proj_bias, self.prec)[E:]
-            ops.cross_kv_prefill(mem, w, b, row_seq, row_pos, self.cross_off, self.cross_len, self.k_cross[i], self.v_cross[i],
+            ops.cross_kv_prefill(mem, w, b, row_seq, row_pos, pre_off, pre_len, self.k_cross[i], self.v_cross[i],
                                  H, self.dh, dhp, round_bf16=self.bf)
-        self.B, self.lens = B, list(lens)
+        self.B, self.lens = B, [l for l in lens for _ in range(G)]
         self.cross_nsplit = max(1, -(-max(lens) // self.CROSS_CHUNK))
         need = B * H * max(self.cross_nsplit, self.self_nsplit) * (dhp + 2)
         if self.partial is None or self.partial.numel() < need:
@@ -313,6 +318,30 @@ class DecodeEngine:
         cur.wait_stream(self.stream)
         return out
 
+    # ---- GRPOViTOMR.cached_forward_rollout_policy (models.py:988-1049) ---------------------------------------------------------
+    def sample(self, max_actions, top_k, temperature, uniforms=None, poll=16, use_graph=True):
+        """Up to max_actions-1 sampling steps (top-k, temperature, inverse-CDF draw from `uniforms` (B, max_actions) in [0,1) - drawn from
+        torch's generator when None).  Returns views seqs (B, max_actions), logprobs (B, max_actions) and the number of steps run."""
+        if max_actions > self.Tmax:
+            raise RuntimeError(f"{max_actions} decoding steps is too long for max sequence length of {self.Tmax}")
+        B = self.B
+        if getattr(self, "uniforms", None) is None:
+            self.uniforms = torch.zeros(self.Bmax, self.Tmax, dtype=torch.float32, device=self.device)
+        if uniforms is None:
+            uniforms = torch.rand(B, max_actions, device=self.device)
+        assert uniforms.shape == (B, max_actions)
+        self.uniforms[:B, :max_actions] = uniforms.to(device=self.device, dtype=torch.float32)
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        self._sampler = (int(top_k), float(temperature))
+        try:
+            with torch.cuda.stream(self.stream):
+                out = self._greedy_on_stream(max_actions, poll, use_graph, None)
+        finally:
+            self._sampler = None
+        cur.wait_stream(self.stream)
+        return out
+
     def greedy_chunks(self, max_len, chunk):
         """Generator over the greedy loop in chunks of `chunk` tokens (streamed inference): yields (tokens_done, all_finished)
         after each chunk; the decode graph is replayed on the engine's stream, the caller's stream waits for it."""
@@ -348,15 +377,24 @@ class DecodeEngine:
 
     STEPS_PER_GRAPH = 8   # a graph replay costs ~10-15 us of launch latency: amortise it over several decode steps
 
+    def _step(self, st):
+        """One decode step on the current stream: greedy, or (self._sampler = (top_k, temperature)) a sampling step."""
+        smp = getattr(self, "_sampler", None)
+        if smp is None:
+            _lib.check(_lib.lib().acai_decode_step(ctypes.byref(self._desc), st), "acai_decode_step")
+        else:
+            _lib.check(_lib.lib().acai_decode_sample_step(ctypes.byref(self._desc), self.uniforms.data_ptr(), int(smp[0]), float(smp[1]), st),
+                       "acai_decode_sample_step")
+
     def ensure_graph(self, nsteps=1):
         """hipGraph of `nsteps` consecutive decode steps for the current (B, cross split) configuration.  Must run on self.stream."""
         B = self.B
-        key = (B, self.cross_nsplit, nsteps)
+        key = (B, self.cross_nsplit, nsteps, getattr(self, "_sampler", None))
         g = self.graphs.get(key)
         if g is None:
             st = ops._st()
             # warm-up launch outside capture (first-use code-object load must not happen inside a capture), then re-arm
-            _lib.check(_lib.lib().acai_decode_step(ctypes.byref(self._desc), st), "acai_decode_step")
+            self._step(st)
             torch.cuda.current_stream().synchronize()
             self.arm(B)
             torch.cuda.current_stream().synchronize()
@@ -364,7 +402,7 @@ class DecodeEngine:
             g.begin()
             try:
                 for _ in range(nsteps):
-                    _lib.check(_lib.lib().acai_decode_step(ctypes.byref(self._desc), st), "acai_decode_step")
+                    self._step(st)
             finally:
                 g.end()
             self.graphs[key] = g
@@ -375,7 +413,7 @@ class DecodeEngine:
         if not use_graph:
             st = ops._st()
             for _ in range(n):
-                _lib.check(_lib.lib().acai_decode_step(ctypes.byref(self._desc), st), "acai_decode_step")
+                self._step(st)
             return
         big = self.STEPS_PER_GRAPH
         while n >= big:

@@ -222,10 +222,11 @@ class CachedTransformerDecoder(nn.TransformerDecoder):
         self.__dict__["_pending"] = encoder_memory
         self.engine(encoder_memory.device).reset_self_cache()
 
-    def prepare_caches_packed(self, mem32, memb, lens):
-        """Packed fast path used by the inference entry points: memory is a ragged token stream."""
+    def prepare_caches_packed(self, mem32, memb, lens, group_size=1):
+        """Packed fast path used by the inference entry points: memory is a ragged token stream.  group_size > 1: each memory serves
+        that many consecutive decode rows (GRPO rollouts of one image) with ONE copy of its cross K/V."""
         self.__dict__["_pending"] = None
-        self.engine(mem32.device if mem32 is not None else memb.device).prepare(mem32, memb, lens)
+        self.engine(mem32.device if mem32 is not None else memb.device).prepare(mem32, memb, lens, group_size=group_size)
 
     def _materialise(self, memory_key_padding_mask):
         mem = self.__dict__["_pending"]

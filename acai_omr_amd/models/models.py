@@ -506,6 +506,92 @@ class ViTOMR(nn.Module):
         yield {"type": InferenceEvent.INFERENCE_FINISH.value, "payload": {"sequence": seqs, "log_probs": lps, "mask": mask}}
 
 
+class GRPOViTOMR(ViTOMR):
+    """ViTOMR prepared for GRPO (M:840-1049): the rollout policy - sampling decode with KV caching - and the helpers around it.  The reward
+    functions and the GRPO training loop itself stay outside the hot path; the rollout decode is SURVEY 8f-1."""
+
+    def __init__(self, encoder, transition_head, decoder, teacher_forced_state_dict):
+        super().__init__(encoder, transition_head, decoder)
+        if isinstance(self.encoder, FineTuneOMREncoder):
+            teacher_forced_state_dict = self.convert_teacher_forced_state_dict(teacher_forced_state_dict, encoder.num_frozen_layers)
+            self.encoder = OMREncoder(self.encoder.patch_size, self.encoder.pe_max_height, self.encoder.pe_max_width, self.encoder.num_layers,
+                                      self.encoder.hidden_dim, **encoder.superclass_kwargs)
+        self.load_state_dict(teacher_forced_state_dict)
+        self.freeze_component(self.encoder)
+        self.freeze_component(self.transition_head)
+
+    def freeze_component(self, component):
+        for param in component.parameters():
+            param.requires_grad = False
+        for child in component.modules():
+            if isinstance(child, nn.Dropout):
+                child.p = 0.0
+
+    def convert_teacher_forced_state_dict(self, teacher_forced_state_dict, num_frozen_layers):
+        """frozen_blocks / fine_tune_blocks keys -> one encoder_blocks stack, fine-tune layer numbers shifted by num_frozen_layers (M:860-880)."""
+        converted = {}
+        pat = re.compile(r"(?:\w|\.)+?(\d+)(?:\w|\.)+")
+        for name in teacher_forced_state_dict.keys():
+            if "frozen_blocks" in name:
+                new = name.replace("frozen_blocks", "encoder_blocks")
+            elif "fine_tune_blocks" in name:
+                new = name.replace("fine_tune_blocks", "encoder_blocks")
+                m = pat.match(name)
+                if m:
+                    n = int(m.group(1))
+                    new = new.replace(f"layers.{n}", f"layers.{n + num_frozen_layers}")
+            else:
+                new = name
+            converted[new] = teacher_forced_state_dict[name]
+        return converted
+
+    def expand_img_latent_for_rollout(self, img_latent, latent_attention_mask, group_size):
+        img_latent = img_latent.unsqueeze(1).expand(-1, group_size, -1, -1).flatten(start_dim=0, end_dim=1)
+        latent_attention_mask = latent_attention_mask.unsqueeze(1).expand(-1, group_size, -1).flatten(start_dim=0, end_dim=1)
+        return img_latent, latent_attention_mask
+
+    def prepare_rollouts_for_policy_theta(self, rollouts, rollout_mask):
+        rollout_lens = rollout_mask.sum(dim=-1, keepdim=True)
+        right_shifted_rollout_lens = rollout_lens - 1
+        rollout_attention_mask = torch.arange(int(torch.max(right_shifted_rollout_lens)), device=rollouts.device).repeat([rollouts.shape[0], 1])
+        rollout_attention_mask = rollout_attention_mask >= right_shifted_rollout_lens
+        return rollouts[:, :-1], rollout_attention_mask
+
+    def forward_teacher_forced(self, img_latent, latent_attention_mask, lmx_seqs, checkpoint_grads):
+        input_seqs, target_seqs, lmx_attention_mask = batchify_and_split_lmx_seqs(lmx_seqs, self.decoder.pad_idx, img_latent.device)
+        pred = self.decoder(input_seqs, img_latent, lmx_attention_mask, latent_attention_mask, checkpoint_grads=checkpoint_grads)
+        return pred, target_seqs
+
+    def batch_policy_inference(self, imgs, max_actions, top_k, temperature):
+        img_latent, latent_attention_mask = self.encoder(imgs)
+        # the reference calls self.forward_rollout_policy here, a method it does not define (M:977); the cached policy is what it means
+        return self.cached_forward_rollout_policy(img_latent, latent_attention_mask, max_actions, top_k, temperature)
+
+    def cached_forward_rollout_policy(self, img_latent, latent_attention_mask, max_actions=768, top_k=50, temperature=1.2, group_size=None,
+                                      uniforms=None):
+        """Sampling rollouts with KV caching (M:988-1049): per step keep the top_k logits, draw from softmax(kept / temperature), record
+        log_softmax(kept)[drawn]; rows stop mattering after their first <eos>.  Returns rollouts (R, T') int64, rollout_log_probs (R, T') fp32,
+        rollout_mask (R, T') bool with padding / zero log-probs outside the mask.
+
+        The whole loop is replayed hipGraphs of `acai_decode_sample_step`.  torch.multinomial's random stream cannot be reproduced: the draws
+        are inverse-CDF samples from `uniforms` (R, max_actions) in [0, 1), taken from torch's generator when None (so torch.manual_seed makes
+        a rollout reproducible).  group_size (extension): img_latent rows r*group_size .. are the copies expand_img_latent_for_rollout made of
+        one image; their cross K/V is then projected and stored once per image instead of once per rollout."""
+        blocks = self.decoder.decoder_blocks
+        if not isinstance(blocks, CachedTransformerDecoder):
+            raise RuntimeError("Trying to use cached inference pathway with an uncached TransformerDecoder instance")
+        G = 1 if group_size is None else int(group_size)
+        if img_latent.shape[0] % G:
+            raise ValueError(f"{img_latent.shape[0]} rollout rows are not a multiple of group_size {G}")
+        lat = img_latent[::G] if G > 1 else img_latent
+        msk = latent_attention_mask[::G] if (G > 1 and latent_attention_mask is not None) else latent_attention_mask
+        mem32, lens = EG.unpad_rows(lat, msk)
+        blocks.prepare_caches_packed(mem32, None, lens, group_size=G)
+        eng = blocks.engine(self.decoder.pos_embedding.device)
+        seqs, lps, _ = eng.sample(max_actions, top_k, temperature, uniforms=uniforms)
+        return self.mask_and_clip_seqs(seqs.clone(), lps.clone())
+
+
 class TeacherForcedViTOMR(ViTOMR):
     """ViTOMR assembled from a (pre-trained MAE) encoder, a transition head and an OMRDecoder (M:649-781)."""
 

@@ -181,6 +181,11 @@ typedef struct {
  * 12x cached_forward, final norm, unembed, argmax + log_softmax gather, seqs[:,t] / logprobs[:,t] update,
  * finished flags, ++*step.  Enqueues only kernels: capture it in a hipGraph and replay. */
 int acai_decode_step(const AcaiDecoder *dec, void *stream);
+/* One SAMPLING decode step for every sequence (GRPOViTOMR.cached_forward_rollout_policy, acai_omr/models/models.py:988-1049): as
+ * acai_decode_step, but the next token is drawn from softmax(top_k(logits) / temperature) and its log-probability is taken under
+ * softmax(top_k(logits)) (models.py:1006-1019).  The draw is the inverse CDF of uniforms[b * max_len + t] over the kept logits in
+ * descending order (ties: lower index first), 1 <= top_k <= 64: torch.multinomial's random stream is replaced by caller-supplied uniforms. */
+int acai_decode_sample_step(const AcaiDecoder *d, const float *uniforms, int top_k, float temperature, void *stream);
 /* The same without the token bookkeeping: logits for caller-supplied tokens/time_step (OMRDecoder.cached_generate). */
 int acai_decode_logits(const AcaiDecoder *dec, const int64_t *tokens, int time_step, void *stream);
 

@@ -501,3 +501,24 @@ def mae_loss(pred, loss_mask, target):
     loss = ((pred - t) ** 2).mean(dim=-1)
     lm = loss_mask.to(loss.dtype)
     return (loss * lm).sum() / lm.sum()
+
+
+# ---- GRPO rollout policy (reference acai_omr/models/models.py:988-1049) ------------------------------------------------------------------
+def rollout_sample_step(logits, u, top_k, temperature, round_lp=False):
+    """One sampling step on (R, V) logits with uniforms u (R,): top-k filter (M:1003), softmax(kept / temperature) (M:1006-1007), draw,
+    log_softmax(kept)[drawn] (M:1017-1018).  The reference draws with torch.multinomial; this restatement - and the HIP kernel - draw by
+    inverse CDF over the kept logits in descending order (ties: lower index first), which has the same distribution."""
+    logits = logits.float()
+    vals, idx = torch.sort(logits, dim=-1, descending=True, stable=True)
+    vals, idx = vals[:, :top_k], idx[:, :top_k]
+    m = vals[:, :1]
+    pT = torch.exp((vals - m) / temperature)
+    cdf = torch.cumsum(pT, dim=-1)
+    target = u.float().unsqueeze(1) * pT.sum(-1, keepdim=True)
+    hit = cdf > target
+    r = torch.where(hit.any(-1), hit.float().argmax(-1), torch.full((logits.shape[0],), vals.shape[1] - 1))
+    tok = idx.gather(-1, r.unsqueeze(1)).squeeze(1)
+    lp = (vals.gather(-1, r.unsqueeze(1)).squeeze(1) - m.squeeze(1)) - torch.log(torch.exp(vals - m).sum(-1))
+    if round_lp:
+        lp = lp.to(torch.bfloat16).float()
+    return tok, lp

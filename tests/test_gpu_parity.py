@@ -335,3 +335,69 @@ def test_streamed_inference_events_match_batch_inference(dev):
         with torch.no_grad():
             lat, msk = m.encoder(fx["imgs"])
             list(m.streamed_cached_greedy_generate(m.transition_head(lat), msk))
+
+
+@pytest.mark.parametrize("cache_dtype", [torch.float, torch.bfloat16])
+def test_grpo_rollout_policy_sampling(dev, cache_dtype):
+    """GRPOViTOMR.cached_forward_rollout_policy (models.py:988-1049) on the graph-replayed sampling step: every drawn token and log-prob
+    equals the oracle's restatement of the step (top-k, temperature softmax, inverse-CDF draw, un-tempered log-softmax) applied to the
+    per-step logits of the already reference-checked cached_generate path with the same uniforms; top_k = 1 degenerates to the greedy
+    decode; rollouts that share one image's cross K/V (group_size) equal the materialised-copies form; draws follow the softmax."""
+    import oracle.vitomr_oracle as O
+    from acai_omr_amd.models.models import GRPOViTOMR, OMREncoder
+    fx = load_golden("vitomr_small")
+    cfg = fx["cfg"]
+    base = build_vitomr(cfg, fx["state_dict"], dev, cache_dtype, max_batch=32)
+    g = GRPOViTOMR(base.encoder, base.transition_head, base.decoder, base.state_dict()).to(dev).eval()
+    assert isinstance(g.encoder, OMREncoder) and not any(p.requires_grad for p in g.encoder.parameters())
+    assert all(p.requires_grad for p in g.decoder.parameters())
+    bf = cache_dtype == torch.bfloat16
+    G, T = 3, cfg["gen_len"]
+    with torch.no_grad():
+        lat0, mask0 = base.encoder(fx["imgs"])
+        lat, mask = g.encoder(fx["imgs"])
+        assert md(lat, lat0) < 1e-5 and torch.equal(mask, mask0)       # frozen/fine-tune stacks merged into one encoder stack
+        mem = g.transition_head(lat)
+        mem_x, mask_x = g.expand_img_latent_for_rollout(mem, mask, G)
+        R = mem_x.shape[0]
+        u = torch.rand(R, T, generator=torch.Generator().manual_seed(7))
+        from torch.amp import autocast
+        with autocast(device_type="cuda", dtype=torch.bfloat16, enabled=bf):
+            r_flat = g.cached_forward_rollout_policy(mem_x, mask_x, max_actions=T, top_k=50, temperature=1.2, uniforms=u)
+            r_grp = g.cached_forward_rollout_policy(mem_x, mask_x, max_actions=T, top_k=50, temperature=1.2, uniforms=u, group_size=G)
+        for a, b in zip(r_flat, r_grp):
+            assert torch.equal(a, b)
+        rollouts, lps, rmask = (t.cpu() for t in r_flat)
+        assert rollouts.shape[0] == R and rollouts.dtype == torch.int64 and torch.equal(rollouts[:, 0], torch.zeros(R, dtype=torch.long))
+        assert bool((rollouts[~rmask] == 1).all()) and bool((lps[~rmask] == 0).all())
+        # replay the drawn tokens through cached_generate and restate every draw with the oracle
+        with autocast(device_type="cuda", dtype=torch.bfloat16, enabled=bf):
+            g.decoder.prepare_caches(mem_x)
+            checked = 0
+            for t in range(1, rollouts.shape[1]):
+                lg = g.decoder.cached_generate(rollouts[:, t - 1:t].to(dev), t, mask_x).squeeze(1)
+                tok, lp = O.rollout_sample_step(lg.float().cpu(), u[:, t], 50, 1.2, round_lp=bf)
+                live = rmask[:, t]
+                assert torch.equal(tok[live], rollouts[live, t]), t
+                assert md(lp[live], lps[live, t]) < (2e-2 if bf else 1e-5), t
+                checked += int(live.sum())
+        assert checked > R
+        # top_k = 1: the greedy decode, log-prob log_softmax over one kept logit = 0
+        with autocast(device_type="cuda", dtype=torch.bfloat16, enabled=bf):
+            seqs, _, smask = g.cached_greedy_generate(mem, mask, max_len=T)
+            r1, lp1, m1 = g.cached_forward_rollout_policy(mem, mask, max_actions=T, top_k=1, temperature=0.7)
+        assert torch.equal(r1, seqs) and torch.equal(m1, smask) and float(lp1.abs().max()) == 0.0
+        # the draw follows softmax(top_k / temperature): 32 rollouts of image 0, first step, a few hundred draws
+        if not bf:
+            torch.manual_seed(0)
+            m1x, k1x = g.expand_img_latent_for_rollout(mem[:1], mask[:1], 32)
+            counts = torch.zeros(len(VOCAB_LIST := open(VOCAB).read().split()), dtype=torch.float64)
+            for _ in range(12):
+                ro, _, _ = g.cached_forward_rollout_policy(m1x, k1x, max_actions=2, top_k=5, temperature=1.0, group_size=32)
+                counts += torch.bincount(ro[:, 1].cpu(), minlength=counts.numel()).double()
+            g.decoder.prepare_caches(mem[:1])
+            lg = g.decoder.cached_generate(torch.zeros(1, 1, dtype=torch.long, device=dev), 1, mask[:1]).squeeze(1).float().cpu()[0]
+            top = torch.topk(lg, 5)
+            probs = torch.zeros_like(counts)
+            probs[top.indices] = torch.softmax(top.values.double(), 0)
+            assert float((counts / counts.sum() - probs).abs().max()) < 0.12 and float(counts[probs == 0].sum()) == 0
