@@ -35,7 +35,7 @@ class AcaiAdamWGroup(Structure):
 class AcaiDecoder(Structure):
     _fields_ = [(n, c_int32) for n in (
         "B", "E", "H", "dh", "dhp", "F", "V", "L", "Tmax", "dtype", "flags", "max_len",
-        "self_chunk", "cross_chunk", "self_nsplit", "cross_nsplit", "bos", "pad", "eos", "reserved")] + [
+        "self_chunk", "cross_chunk", "self_nsplit", "cross_nsplit", "bos", "pad", "eos", "cross_group")] + [
         ("layers", POINTER(AcaiDecLayer))] + [(n, c_void_p) for n in (
             "emb", "pos", "fn_w", "fn_b", "unembed_w", "unembed_b", "cross_off", "cross_len", "seqs", "logprobs",
             "step", "finished", "x", "xn", "qkv", "attn", "proj", "hid", "logits", "partial", "tickets", "stats")]

@@ -218,7 +218,7 @@ class DecodeEngine:
             b = self.wc.b(ca.in_proj_bias, self.prec)[E:]
             ops.cross_kv_prefill(mem, w, b, row_seq, row_pos, pre_off, pre_len, self.k_cross[i], self.v_cross[i],
                                  H, self.dh, dhp, round_bf16=self.bf)
-        self.B, self.lens = B, [l for l in lens for _ in range(G)]
+        self.B, self.lens, self.group = B, [l for l in lens for _ in range(G)], G
         self.cross_nsplit = max(1, -(-max(lens) // self.CROSS_CHUNK))
         need = B * H * max(self.cross_nsplit, self.self_nsplit) * (dhp + 2)
         if self.partial is None or self.partial.numel() < need:
@@ -258,6 +258,7 @@ class DecodeEngine:
         d.dtype = _lib.ACAI_BF16 if self.bf else _lib.ACAI_F32
         d.flags = _lib.GEMM_ROUND_BF16 if self.bf else 0
         d.max_len = self.Tmax
+        d.cross_group = getattr(self, "group", 1)
         d.self_chunk, d.cross_chunk, d.self_nsplit, d.cross_nsplit = self.SELF_CHUNK, self.CROSS_CHUNK, self.self_nsplit, self.cross_nsplit
         d.layers = ctypes.cast(layers, ctypes.POINTER(_lib.AcaiDecLayer))
         top = {}
@@ -389,7 +390,7 @@ class DecodeEngine:
     def ensure_graph(self, nsteps=1):
         """hipGraph of `nsteps` consecutive decode steps for the current (B, cross split) configuration.  Must run on self.stream."""
         B = self.B
-        key = (B, self.cross_nsplit, nsteps, getattr(self, "_sampler", None))
+        key = (B, self.cross_nsplit, nsteps, getattr(self, "_sampler", None), getattr(self, "group", 1))
         g = self.graphs.get(key)
         if g is None:
             st = ops._st()

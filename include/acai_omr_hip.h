@@ -159,7 +159,8 @@ typedef struct {
     int32_t B, E, H, dh, dhp, F, V, L, Tmax, dtype, flags, max_len;
     int32_t self_chunk, cross_chunk;    /* keys per attention workgroup */
     int32_t self_nsplit, cross_nsplit;  /* workgroups per (b, h) */
-    int32_t bos, pad, eos, reserved;
+    int32_t bos, pad, eos;
+    int32_t cross_group;   /* > 1: every `cross_group` consecutive rows share one memory (GRPO rollouts of one image): its K/V is streamed once per group */
     const AcaiDecLayer *layers;         /* host array of L entries */
     const float *emb;                   /* vocab_embedding.weight [V,E] fp32 */
     const float *pos;                   /* decoder pos_embedding [Tmax,E] fp32 */

@@ -337,15 +337,16 @@ def test_streamed_inference_events_match_batch_inference(dev):
             list(m.streamed_cached_greedy_generate(m.transition_head(lat), msk))
 
 
+@pytest.mark.parametrize("name", ["vitomr_small", "vitomr_dh64"])
 @pytest.mark.parametrize("cache_dtype", [torch.float, torch.bfloat16])
-def test_grpo_rollout_policy_sampling(dev, cache_dtype):
+def test_grpo_rollout_policy_sampling(dev, cache_dtype, name):
     """GRPOViTOMR.cached_forward_rollout_policy (models.py:988-1049) on the graph-replayed sampling step: every drawn token and log-prob
     equals the oracle's restatement of the step (top-k, temperature softmax, inverse-CDF draw, un-tempered log-softmax) applied to the
     per-step logits of the already reference-checked cached_generate path with the same uniforms; top_k = 1 degenerates to the greedy
     decode; rollouts that share one image's cross K/V (group_size) equal the materialised-copies form; draws follow the softmax."""
     import oracle.vitomr_oracle as O
     from acai_omr_amd.models.models import GRPOViTOMR, OMREncoder
-    fx = load_golden("vitomr_small")
+    fx = load_golden(name)
     cfg = fx["cfg"]
     base = build_vitomr(cfg, fx["state_dict"], dev, cache_dtype, max_batch=32)
     g = GRPOViTOMR(base.encoder, base.transition_head, base.decoder, base.state_dict()).to(dev).eval()
@@ -365,8 +366,9 @@ def test_grpo_rollout_policy_sampling(dev, cache_dtype):
         with autocast(device_type="cuda", dtype=torch.bfloat16, enabled=bf):
             r_flat = g.cached_forward_rollout_policy(mem_x, mask_x, max_actions=T, top_k=50, temperature=1.2, uniforms=u)
             r_grp = g.cached_forward_rollout_policy(mem_x, mask_x, max_actions=T, top_k=50, temperature=1.2, uniforms=u, group_size=G)
-        for a, b in zip(r_flat, r_grp):
-            assert torch.equal(a, b)
+        # rows aliasing one stored K/V (and, with ACAI_DECODE_GROUP_KERNEL=1, the grouped kernel) differ from the copies form by rounding at most
+        assert torch.equal(r_flat[0], r_grp[0]) and torch.equal(r_flat[2], r_grp[2])
+        assert md(r_flat[1], r_grp[1]) < (2e-2 if bf else 1e-4)
         rollouts, lps, rmask = (t.cpu() for t in r_flat)
         assert rollouts.shape[0] == R and rollouts.dtype == torch.int64 and torch.equal(rollouts[:, 0], torch.zeros(R, dtype=torch.long))
         assert bool((rollouts[~rmask] == 1).all()) and bool((lps[~rmask] == 0).all())
