@@ -156,7 +156,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=2048)
-    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--cpu-steps", type=int, default=192, help="timed CPU-oracle decode steps (192 x 8 tokens is ~10 s on 16 cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--encoder-dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--mae-batch", type=int, default=32)
