@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -302,8 +303,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 // bounds the short-K GEMMs (K = 512..768: 8-12 K-steps per output tile).  Each wave therefore transposes its 64x64 block through `stg`
 // (its share of the now free LDS stages), 32 rows at a time, and writes 16 bytes per lane along the rows.  Bias and bf16 rounding are applied
 // on the way in; GELU (optionally keeping the pre-activation in `aux`), the GELU-derivative product and the fp32 residual on the way out.
+template <int ROWS = 32>   // rows staged per pass: 32 (8.5 KB of LDS per wave) or 16 (4.25 KB: the persistent kernel has one free stage)
 __device__ __forceinline__ void gemm_vec_epilogue(const GemmArgs &g, const f32x16 (&acc)[2][2], float *stg, int bm0, int bn0, int wm, int wn, int lane) {
     constexpr int EP = 68;  // floats per staged row (64 + 4: 16-byte aligned rows, conflict-light)
+    constexpr int NP = 32 / ROWS;   // passes per 32-row block
     const int lr = lane & 31, lh = lane >> 5;
     const int ldc_e = g.ldc, n_valid = g.N - (bn0 + wn * 64);
     const bool do_gelu = g.flags & ACAI_GEMM_GELU, do_round = g.flags & ACAI_GEMM_ROUND_BF16;
@@ -341,23 +344,25 @@ __device__ __forceinline__ void gemm_vec_epilogue(const GemmArgs &g, const f32x1
         if (g.residual) v += *reinterpret_cast<const f32x4 *>(g.residual + (size_t)row * g.ldr + col);
     };
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int ip = 0; ip < 2 * NP; ++ip) {
+        const int i = ip / NP, pass = ip % NP;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = bn0 + wn * 64 + j * 32 + lr;
             const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
+                if (NP == 2 && (e >> 3) != pass) continue;   // 16-row passes: registers 0..7 hold rows 0..15, 8..15 rows 16..31
                 float v = acc[i][j][e] + bv;
                 if (do_round) v = round_bf16(v);
-                stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * EP + j * 32 + lr] = v;
+                stg[((e & 3) + 8 * ((e >> 2) & (NP == 2 ? 1 : 3)) + 4 * lh) * EP + j * 32 + lr] = v;
             }
         }
         // same wave wrote and now reads: LDS operations of a wave complete in order
-        const int row_base = bm0 + wm * 64 + i * 32, col_base = bn0 + wn * 64;
+        const int row_base = bm0 + wm * 64 + i * 32 + pass * ROWS, col_base = bn0 + wn * 64;
         if (g.out_dtype == ACAI_BF16) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
+            for (int it = 0; it < ROWS / 8; ++it) {
                 const int idx = it * 64 + lane, r = idx >> 3, c8 = (idx & 7) * 8;
                 const int row = row_base + r;
                 if (row < g.M && c8 < n_valid) {
@@ -371,7 +376,7 @@ __device__ __forceinline__ void gemm_vec_epilogue(const GemmArgs &g, const f32x1
             }
         } else {
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
+            for (int it = 0; it < ROWS / 4; ++it) {
                 const int idx = it * 64 + lane, r = idx >> 4, c4 = (idx & 15) * 4;
                 const int row = row_base + r;
                 if (row < g.M && c4 < n_valid) {
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2))) v
     }
     // every wave is past the last barrier: both stages are free; a wave stages 32 rows x 68 floats = 8.5 KB
     float *stg = reinterpret_cast<float *>((wave < WM ? lds0 : lds1) + (wave % WM) * (STAGE / WM));
-    gemm_vec_epilogue(g, acc, stg, bm0, bn0, wm, wn, lane);
+    gemm_vec_epilogue<32>(g, acc, stg, bm0, bn0, wm, wn, lane);
 }
 
 // ---- 256x128 tile, 8 waves, THREE LDS stages (144 KB): two K-tiles in flight ------------------------------------------------------------
@@ -638,7 +643,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     }
     // every wave is past the last barrier: both stages are free; a wave stages 32 rows x 68 floats = 8.5 KB
     float *stg = reinterpret_cast<float *>((wave < WM ? lds0 : lds1) + (wave % WM) * (STAGE / WM));
-    gemm_vec_epilogue(g, acc, stg, bm0, bn0, wm, wn, lane);
+    gemm_vec_epilogue<32>(g, acc, stg, bm0, bn0, wm, wn, lane);
 }
 
 // ---- dW = dY^T . X with direct-to-LDS staging (bf16) ----------------------------------------------------------------------------------
@@ -746,6 +751,257 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     gemm_accum_epilogue(g, acc, bm0, bn0, wm, wn, lr, lh);
 }
 
+// ---- persistent 256x128 kernel: the three-stage LDS-DMA ring runs ACROSS output tiles ------------------------------------------------------
+// The per-tile fixed cost of the three-stage kernel is ~9 us (workgroup dispatch, address set-up, the first DMA round trip, epilogue): two
+// thirds of a K = 512 tile (8 K-steps, 4.3 us of MFMA).  Here one workgroup per CU walks a list of tiles (XCD-contiguous ranges, as the
+// non-persistent order) and its producer cursor simply keeps going: while tile i is in its last K-steps and its epilogue, the first two
+// K-tiles of tile i+1 are already in flight.  The epilogue stages through the ring slot the last K-step just freed (16 rows per pass), behind
+// one extra barrier; the step after an epilogue drains vmcnt to 0 (output stores share the counter with the DMA).
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_pers_kernel(GemmArgs g) {
+    constexpr int BK = ROWB / sizeof(T);
+    constexpr int WM = 4, BMT = 256, NW = 8, GA = BMT / 8 / NW, GW = BN / 8 / NW, STAGE = (BMT + BN) * ROWB;
+    static_assert(GA + GW == 6, "counted wait assumes six LDS-DMA instructions per wave and K-tile");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+    const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BMT - 1) / BMT, ntiles = nbn * nbm;
+    // my tiles: XCD x = blockIdx % 8 owns a contiguous range, its workgroups interleave inside it
+    const int w = blockIdx.x, nwg = gridDim.x, xcd = w % 8, j0 = w / 8;
+    const int per_xcd = (nwg - xcd + 7) / 8;
+    const int tq = ntiles / 8, tr = ntiles % 8;
+    const int t_start = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, t_count = tq + (xcd < tr ? 1 : 0);
+    const int n_my = j0 < t_count ? (t_count - j0 + per_xcd - 1) / per_xcd : 0;
+    const int nkt = g.K / BK, total = n_my * nkt;
+    if (total == 0) return;
+    const T *A = reinterpret_cast<const T *>(g.A);
+    const T *W = reinterpret_cast<const T *>(g.W);
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr)lds;
+
+    // ---- producer cursor ----
+    const int grow = lane >> 3;
+    const T *srcA[GA], *srcW[GW];
+    int p_tile = 0, p_kt = 0;
+    auto set_tile = [&](int ti) {
+        const int t = t_start + j0 + ti * per_xcd, bm0 = (t / nbn) * BMT, bn0 = (t % nbn) * BN;
+#pragma unroll
+        for (int i = 0; i < GA; ++i) {
+            const int row = (wave * GA + i) * 8 + grow, gslot = (lane & 7) ^ ((row >> 1) & 7);
+            srcA[i] = A + (size_t)min(bm0 + row, g.M - 1) * g.lda + gslot * (16 / sizeof(T));
+        }
+#pragma unroll
+        for (int i = 0; i < GW; ++i) {
+            const int row = (wave * GW + i) * 8 + grow, gslot = (lane & 7) ^ ((row >> 1) & 7);
+            srcW[i] = W + (size_t)min(bn0 + row, g.N - 1) * g.ldw + gslot * (16 / sizeof(T));
+        }
+    };
+    auto issue = [&](int slot) {   // next K-tile of the producer cursor -> ring slot
+        const uint32_t lb = lds_base + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < GA; ++i) {
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lb + (wave * GA + i) * 1024);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(srcA[i] + (size_t)p_kt * BK) : "memory", "m0");
+        }
+#pragma unroll
+        for (int i = 0; i < GW; ++i) {
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lb + BMT * ROWB + (wave * GW + i) * 1024);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(srcW[i] + (size_t)p_kt * BK) : "memory", "m0");
+        }
+        if (++p_kt == nkt) {
+            p_kt = 0;
+            if (++p_tile < n_my) set_tile(p_tile);
+        }
+    };
+
+    f32x16 acc[2][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    };
+    auto compute = [&](const unsigned char *sa) {
+        const unsigned char *sb = sa + BMT * ROWB;
+        uint4 fa[2][2], fb[2][2];
+        auto frags = [&](int s, uint4 (&xa)[2], uint4 (&xb)[2]) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ra = wm * 64 + i * 32 + lr, rb = wn * 64 + i * 32 + lr;
+                xa[i] = *reinterpret_cast<const uint4 *>(sa + ra * ROWB + (((s * 2 + lh) ^ ((ra >> 1) & 7)) << 4));
+                xb[i] = *reinterpret_cast<const uint4 *>(sb + rb * ROWB + (((s * 2 + lh) ^ ((rb >> 1) & 7)) << 4));
+            }
+        };
+        frags(0, fa[0], fb[0]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s + 1 < 4) frags(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (sizeof(T) == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][i]), __builtin_bit_cast(bf16x8, fb[s & 1][j]), acc[i][j], 0, 0, 0);
+                    } else {
+                        const f32x4 a4 = __builtin_bit_cast(f32x4, fa[s & 1][i]), b4 = __builtin_bit_cast(f32x4, fb[s & 1][j]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+    };
+
+    set_tile(0);
+    issue(0);
+    if (total > 1) issue(1);
+    zero_acc();
+    int c_tile = 0, c_kt = 0, slot = 0;
+    bool drained = false;   // the previous step ended with an epilogue: its stores are still counted in vmcnt
+    for (int q = 0; q < total; ++q) {
+        if (!drained && q + 1 < total)
+            asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        drained = false;
+        if (q + 2 < total) issue(slot == 0 ? 2 : slot - 1);   // slot of step q + 2 = (slot + 2) % 3
+        compute(lds + slot * STAGE);
+        if (++c_kt == nkt) {
+            c_kt = 0;
+            const int t = t_start + j0 + c_tile * per_xcd, bm0 = (t / nbn) * BMT, bn0 = (t % nbn) * BN;
+            if (EPI != 0 || !g.vec_epi) {
+                gemm_epilogue<EPI, false>(g, acc, bm0, bn0, wm, wn, lr, lh);
+            } else {
+                asm volatile("s_barrier" ::: "memory");   // every wave is done reading this slot: it becomes the staging space
+                float *stg = reinterpret_cast<float *>(lds + slot * STAGE + wave * (STAGE / NW));
+                gemm_vec_epilogue<16>(g, acc, stg, bm0, bn0, wm, wn, lane);
+            }
+            zero_acc();
+            ++c_tile;
+            drained = true;
+        }
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+}
+
+// ---- 256x256 tile, 8 waves x (128 x 64), two 64 KB LDS-DMA stages -----------------------------------------------------------------------
+// A CU takes in at most ~60-70 GB/s through the LDS-DMA path.  A 256x128 K-step stages 48 KB for 1024 MFMA cycles per SIMD (~0.54 us at
+// 1.9 GHz): 89 GB/s would be needed, so those kernels run staging-bound at ~45 % MFMA utilisation however deep the ring is.  The 256x256
+// tile stages 64 KB for 2048 MFMA cycles (59 GB/s): the first shape on which the matrix cores, not the staging path, can set the pace.
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_256_kernel(GemmArgs g) {
+    constexpr int BK = ROWB / sizeof(T);
+    constexpr int BT = 256, STAGE = 2 * BT * ROWB;   // 64 KB: A image (256 rows) then W image (256 rows)
+    __shared__ __attribute__((aligned(16))) unsigned char lds0[STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char lds1[STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3, lr = lane & 31, lh = lane >> 5;
+    const int nbn = (g.N + BT - 1) / BT, nbm = (g.M + BT - 1) / BT, nwg = nbn * nbm;
+    int pid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = pid % 8, idx = pid / 8;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm0 = (pid / nbn) * BT, bn0 = (pid % nbn) * BT;
+    const T *A = reinterpret_cast<const T *>(g.A);
+    const T *W = reinterpret_cast<const T *>(g.W);
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int grow = lane >> 3;
+    const T *srcA[4], *srcW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + grow, gslot = (lane & 7) ^ ((row >> 1) & 7);
+        srcA[i] = A + (size_t)min(bm0 + row, g.M - 1) * g.lda + gslot * (16 / sizeof(T));
+        srcW[i] = W + (size_t)min(bn0 + row, g.N - 1) * g.ldw + gslot * (16 / sizeof(T));
+    }
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    typedef const __attribute__((address_space(1))) void *glb_ptr;
+    auto issue = [&](int kt, unsigned char *base) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_ptr)(srcA[i] + (size_t)kt * BK), (lds_ptr)(base + (wave * 4 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(srcW[i] + (size_t)kt * BK), (lds_ptr)(base + BT * ROWB + (wave * 4 + i) * 1024), 16, 0, 0);
+        }
+    };
+    auto compute = [&](const unsigned char *sa) {
+        const unsigned char *sb = sa + BT * ROWB;
+        uint4 fa[2][4], fb[2][2];
+        auto frags = [&](int s, uint4 (&xa)[4], uint4 (&xb)[2]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ra = wm * 128 + i * 32 + lr;
+                xa[i] = *reinterpret_cast<const uint4 *>(sa + ra * ROWB + (((s * 2 + lh) ^ ((ra >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int rb = wn * 64 + j * 32 + lr;
+                xb[j] = *reinterpret_cast<const uint4 *>(sb + rb * ROWB + (((s * 2 + lh) ^ ((rb >> 1) & 7)) << 4));
+            }
+        };
+        frags(0, fa[0], fb[0]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s + 1 < 4) frags(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (sizeof(T) == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][i]), __builtin_bit_cast(bf16x8, fb[s & 1][j]), acc[i][j], 0, 0, 0);
+                    } else {
+                        const f32x4 a4 = __builtin_bit_cast(f32x4, fa[s & 1][i]), b4 = __builtin_bit_cast(f32x4, fb[s & 1][j]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+    };
+    const int nkt = g.K / BK;
+    issue(0, lds0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 <= nkt; kt += 2) {
+        issue(kt + 1, lds1);
+        compute(lds0);
+        __syncthreads();
+        if (kt + 2 < nkt) issue(kt + 2, lds0);
+        compute(lds1);
+        __syncthreads();
+    }
+    if (kt < nkt) {
+        compute(lds0);
+        __syncthreads();
+    }
+    // epilogue: the wave's 128 x 64 block as two 64 x 64 halves through the shared routines (constant indices only: a run-time index
+    // into acc would push all 128 accumulator registers to scratch)
+    auto epi_half = [&](auto ihc) {
+        constexpr int ih = decltype(ihc)::value;
+        f32x16 half[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) half[i][j] = acc[2 * ih + i][j];
+        const int bmh = bm0 + wm * 128 + ih * 64;
+        if (EPI != 0 || !g.vec_epi) {
+            gemm_epilogue<EPI, false>(g, half, bmh, bn0, 0, wn, lr, lh);
+        } else {
+            float *stg = reinterpret_cast<float *>((wave < 4 ? lds0 : lds1) + (wave & 3) * (STAGE / 4));
+            gemm_vec_epilogue<32>(g, half, stg, bmh, bn0, 0, wn, lane);
+        }
+    };
+    epi_half(std::integral_constant<int, 0>{});
+    epi_half(std::integral_constant<int, 1>{});
+}
+
+int g_gemm_variant = getenv("ACAI_GEMM_VARIANT") ? atoi(getenv("ACAI_GEMM_VARIANT")) : 0;
+
 template <typename T, int EPI, bool TA = false, bool TB = false>
 int launch(const GemmArgs &g, hipStream_t st) {
     constexpr int EPC = 16 / sizeof(T);
@@ -775,17 +1031,26 @@ int launch(const GemmArgs &g, hipStream_t st) {
             return 0;
         }
     }
-    static const char *force_wm = getenv("ACAI_GEMM_WM");   // A/B aid: "2" or "4"
     if (fast && !TA && !TB && g.K % BKG == 0 && !no_glds) {
-        const int nwg4 = cdiv(g.M, 256) * cdiv(g.N, BN);
-        const bool big = force_wm ? atoi(force_wm) == 4 : nwg4 >= 512;
-        static const bool no3 = getenv("ACAI_GEMM_NO_3STAGE") != nullptr;
-        if (big && !no3)
-            hipLaunchKernelGGL((gemm_nt_glds3_kernel<T, EPI>), dim3(nwg4), dim3(512), 0, st, h);
-        else if (big)
-            hipLaunchKernelGGL((gemm_nt_glds_kernel<T, EPI, 4>), dim3(nwg4), dim3(512), 0, st, h);
-        else
-            hipLaunchKernelGGL((gemm_nt_glds_kernel<T, EPI, 2>), dim3(nwg), dim3(256), 0, st, h);
+        // Row-major LDS-DMA kernels.  variant (acai_gemm_set_variant / ACAI_GEMM_VARIANT; tests and A/B runs): 0 auto, 1 128x128 two-stage,
+        // 2 256x128 two-stage, 3 256x128 three-stage, 4 256x128 persistent three-stage ring, 5 256x256 two-stage.
+        static const int n_cu = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        const int nwg4 = cdiv(g.M, 256) * cdiv(g.N, BN), nwg256 = cdiv(g.M, 256) * cdiv(g.N, 256);
+        int v = g_gemm_variant;
+        // auto (tools/bench_gemm.py, bf16): up to 24 K-tiles the persistent ring wins (0.61-0.71 PF on K = 512..768 against 0.53-0.64 for
+        // one tile per workgroup); from 64 K-tiles the 256x256 tile does (1.00-1.02 PF at 4096^3 / 8192^3 against 0.95-0.98); between, the
+        // three-stage 256x128 kernel; small problems keep two 128x128 workgroups per CU.
+        const int ktiles = g.K / BKG;
+        if (v == 0) v = nwg4 >= 512 ? (ktiles <= 24 ? 4 : (ktiles >= 64 && nwg256 >= n_cu ? 5 : 3)) : 1;
+        if (v == 5 && nwg256 < 8) v = 1;
+        if (v == 4 && nwg4 < 8) v = 1;
+        switch (v) {
+            case 5: hipLaunchKernelGGL((gemm_nt_256_kernel<T, EPI>), dim3(nwg256), dim3(512), 0, st, h); break;
+            case 4: hipLaunchKernelGGL((gemm_nt_pers_kernel<T, EPI>), dim3(nwg4 < n_cu ? nwg4 : n_cu), dim3(512), 0, st, h); break;
+            case 3: hipLaunchKernelGGL((gemm_nt_glds3_kernel<T, EPI>), dim3(nwg4), dim3(512), 0, st, h); break;
+            case 2: hipLaunchKernelGGL((gemm_nt_glds_kernel<T, EPI, 4>), dim3(nwg4), dim3(512), 0, st, h); break;
+            default: hipLaunchKernelGGL((gemm_nt_glds_kernel<T, EPI, 2>), dim3(nwg), dim3(256), 0, st, h); break;
+        }
     }
     else if (fast)
         hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, true, TA, TB>), dim3(nwg), dim3(256), 0, st, h);
@@ -796,6 +1061,12 @@ int launch(const GemmArgs &g, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int acai_gemm_set_variant(int variant) {
+    ACAI_CHECK_ARG(variant >= 0 && variant <= 5, "acai_gemm_set_variant: 0 (auto) .. 5");
+    g_gemm_variant = variant;
+    return 0;
+}
 
 extern "C" int acai_gemm_nt_ex(const void *A, int lda, const void *W, int ldw, const float *bias, const float *residual, int ldr,
                                void *C, int ldc, void *aux, int ldaux, int aux_mode, int M, int N, int K, int in_dtype, int out_dtype, int flags,

@@ -40,14 +40,21 @@ def test_gemm_nt(dev, M, N, K, dtype):
     _check_gemm_nt(dev, M, N, K, dtype)
 
 
+@pytest.mark.parametrize("variant", [2, 3, 4, 5])
 @pytest.mark.parametrize("K", [64, 128, 192, 256, 320, 704])
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
-def test_gemm_nt_three_stage_tile(dev, K, dtype):
-    """Shapes with >= 512 tiles of 256x128 take the three-stage LDS-DMA kernel (two K-tiles in flight, counted vmcnt waits): every K-tile
+def test_gemm_nt_three_stage_tile(dev, K, dtype, variant):
+    """The large-tile LDS-DMA kernels, each pinned in turn (256x128 two-stage, three-stage with counted vmcnt waits, persistent ring across
+    tiles, 256x256): every K-tile
     count modulo 3, one to many tiles, ragged M / N edges."""
+    from acai_omr_amd import _lib
     if dtype == "fp32":
         K //= 2   # 32 floats per K-tile: same tile counts
-    _check_gemm_nt(dev, 16384 + 40, 4096 + 24, K, dtype)
+    _lib.check(_lib.lib().acai_gemm_set_variant(variant), "acai_gemm_set_variant")
+    try:
+        _check_gemm_nt(dev, 8192 + 40, 2048 + 24, K, dtype)
+    finally:
+        _lib.lib().acai_gemm_set_variant(0)
 
 
 def _check_gemm_nt(dev, M, N, K, dtype):
