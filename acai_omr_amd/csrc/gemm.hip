@@ -1025,8 +1025,21 @@ int launch(const GemmArgs &g, hipStream_t st) {
     static const bool no_glds = getenv("ACAI_GEMM_NO_GLDS") != nullptr;
     static const bool no_tn = getenv("ACAI_GEMM_NO_TN_GLDS") != nullptr;   // A/B aid
     if constexpr (TA && TB && EPI == 0 && sizeof(T) == 2) {
-        if (fast && !no_tn && !no_glds && h.ksplit > 0 && g.K % 64 == 0 && g.M % 8 == 0 && g.N % 8 == 0 && g.M >= 8 && g.N >= 8) {
-            hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(nwg), dim3(256), 0, st, h);
+        if (fast && !no_tn && !no_glds && h.ksplit > 0 && g.K >= 64 && g.M % 8 == 0 && g.N % 8 == 0 && g.M >= 8 && g.N >= 8) {
+            // token counts that are not a multiple of 64 (16 x 513 decoder tokens): the LDS-DMA kernel takes the whole 64-token tiles, the
+            // register-staged kernel accumulates the remaining rows into the same gradient
+            const int k64 = g.K - g.K % 64;
+            GemmArgs m = h;
+            m.K = k64;
+            hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(nwg), dim3(256), 0, st, m);
+            if (k64 < g.K) {
+                GemmArgs t = h;
+                t.A = reinterpret_cast<const T *>(g.A) + (size_t)k64 * g.lda;
+                t.W = reinterpret_cast<const T *>(g.W) + (size_t)k64 * g.ldw;
+                t.K = g.K - k64;
+                t.ksplit = 1;
+                hipLaunchKernelGGL((gemm_nt_kernel<T, 0, true, true, true>), dim3(cdiv(g.M, BM) * cdiv(g.N, BN)), dim3(256), 0, st, t);
+            }
             ACAI_LAUNCH_CHECK("acai_gemm");
             return 0;
         }

@@ -278,10 +278,12 @@ def colsum(x):
     return out
 
 
-def scatter_add_rows(src, idx, dst):
+def scatter_add_rows(src, idx, dst, shared_row=-1):
+    """dst[idx[r]] += src[r].  shared_row >= 0: the only index that may repeat (everything else is updated without atomics)."""
     _chk(src, "src", torch.float32), _chk(idx, "idx", torch.int32), _chk(dst, "dst", torch.float32)
     assert src.is_contiguous() and dst.is_contiguous() and src.shape[1] == dst.shape[1] and idx.numel() == src.shape[0]
-    _lib.check(_lib.lib().acai_scatter_add_rows(src.data_ptr(), idx.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1], _st()), "acai_scatter_add_rows")
+    _lib.check(_lib.lib().acai_scatter_add_rows(src.data_ptr(), idx.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1], int(shared_row), _st()),
+               "acai_scatter_add_rows")
     return dst
 
 

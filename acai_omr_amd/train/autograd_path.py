@@ -289,10 +289,12 @@ class GatherRowsFn(Function):
     """out[i] = table[idx[i]] (+ add[i]); backward scatter-adds into the table."""
 
     @staticmethod
-    def forward(ctx, table, idx, add):
+    def forward(ctx, table, idx, add, shared_row=-1):
+        """shared_row >= 0: the caller guarantees that no other table row is gathered twice (backward then needs no atomics for them)."""
         ctx.save_for_backward(idx)
         ctx.shape = table.shape
         ctx.has_add = add is not None
+        ctx.shared_row = shared_row
         return ops.gather_rows(table.contiguous(), idx, add)
 
     @staticmethod
@@ -301,8 +303,8 @@ class GatherRowsFn(Function):
         dy = dy.contiguous().float()
         dt = None
         if ctx.needs_input_grad[0]:
-            dt = ops.scatter_add_rows(dy, idx, torch.zeros(ctx.shape, dtype=torch.float32, device=dy.device))
-        return dt, None, (dy if ctx.has_add else None)
+            dt = ops.scatter_add_rows(dy, idx, torch.zeros(ctx.shape, dtype=torch.float32, device=dy.device), shared_row=ctx.shared_row)
+        return dt, None, (dy if ctx.has_add else None), None
 
 
 def pad_rows(packed, lens, fill_row=None):
@@ -495,7 +497,7 @@ def mae_forward(mae, batch, noises=None, packed=False):
         idx.append(torch.where(r < k, r + o, torch.full_like(r, Mk)).to(torch.int32))
         o += k
     dpe = _pe_rows(mae.encoder, mae.decoder_pos_embedding, dims)
-    x32 = GatherRowsFn.apply(table, torch.cat(idx).to(dev), dpe)
+    x32 = GatherRowsFn.apply(table, torch.cat(idx).to(dev), dpe, Mk)   # ids_restore is a permutation: only the mask-token row repeats
     cu = EG.cu_from_lens(lens, dev)
     H = mae.decoder.decoder_blocks.layers[0].self_attn.num_heads
     x32 = encoder_stack(mae.decoder.decoder_blocks, x32, cu, max(lens), H, prec, _wc(mae.decoder), training=mae.training)

@@ -111,8 +111,10 @@ int acai_gelu_fwd(const void *a, void *h, int64_t n, int dtype, void *stream);
 int acai_gelu_bwd(const void *a, const void *dh, void *da, int64_t n, int dtype, void *stream);
 /* out[c] += sum_r x[r,c] (bias gradients); out fp32, accumulated with atomics. */
 int acai_colsum(const void *x, int ld, float *out, int rows, int cols, int dtype, void *stream);
-/* dst[idx[r],:] += src[r,:] (gradients of nn.Embedding M:460, pos_embedding slices M:50, MAE index_select M:114,229). */
-int acai_scatter_add_rows(const float *src, const int32_t *idx, float *dst, int rows, int dim, void *stream);
+/* dst[idx[r],:] += src[r,:] (gradients of nn.Embedding M:460, pos_embedding slices M:50, MAE index_select M:114,229).
+ * shared_row >= 0: the caller guarantees that only that index occurs more than once (the MAE mask token) - the other rows are then
+ * updated without atomics; shared_row < 0: every row through fp32 atomics. */
+int acai_scatter_add_rows(const float *src, const int32_t *idx, float *dst, int rows, int dim, int shared_row, void *stream);
 /* nn.Dropout on a projection output followed by the residual add (torch TransformerEncoderLayer dropout1/dropout2, decoder dropout1-3,
  * transition head M:658): out = residual + keep * x / (1 - p); residual may be NULL (plain dropout, and its own backward on dy).
  * keep mask = counter-based hash of (seed, row, col). */

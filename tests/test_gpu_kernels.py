@@ -236,7 +236,7 @@ def test_gemm_nt_gelu_aux_modes(dev, dtype, shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
-@pytest.mark.parametrize("shape", [(136, 264, 4096), (768, 2304, 8192 + 64), (512, 8, 640), (40, 1000, 192)])
+@pytest.mark.parametrize("shape", [(136, 264, 4096), (768, 2304, 8192 + 64), (512, 8, 640), (40, 1000, 192), (1024, 1024, 8208), (264, 136, 100)])
 def test_gemm_weight_gradient_form(dev, dtype, shape):
     """dW = dY^T X (both operands contraction-major, split-K atomics into an fp32 gradient that may already hold a value): the LDS-DMA
     transposing-read kernel (bf16, token count % 64 == 0) and the register-staged form (fp32 / other shapes) against fp64."""

@@ -373,3 +373,20 @@ def test_fused_adamw_matches_torch(dev):
     oc.step(), od.step(grad_scale=0.125)
     for x, y in zip(pc, pd):
         assert torch.equal(x, y)
+
+
+def test_scatter_add_rows_shared_row(dev):
+    """Row scatter-add with one shared index (the MAE mask token): equals index_add_ and the all-atomics form."""
+    from acai_omr_amd import ops
+    g = torch.Generator().manual_seed(9)
+    rows, dim, table = 3000, 512, 901
+    perm = torch.randperm(900, generator=g)
+    idx = torch.full((rows,), 900, dtype=torch.int32)
+    pos = torch.randperm(rows, generator=g)[:900]
+    idx[pos] = perm.to(torch.int32)
+    src = torch.randn(rows, dim, generator=g).to(dev)
+    ref = torch.zeros(table, dim).index_add_(0, idx.long(), src.cpu())
+    a = ops.scatter_add_rows(src, idx.to(dev), torch.zeros(table, dim, device=dev), shared_row=900)
+    b = ops.scatter_add_rows(src, idx.to(dev), torch.zeros(table, dim, device=dev))
+    assert torch.allclose(a.cpu(), ref, atol=2e-3, rtol=1e-4) and torch.allclose(b.cpu(), ref, atol=2e-3, rtol=1e-4)
+    assert torch.equal(a[:900], b[:900])
