@@ -140,7 +140,7 @@ def bench_mae(dev, rank, world, dist, batch, height, width, steps, dtype):
         dt = float(t.item())
     flop_img = 2.29e12 * (height * width) / (512 * 2048) if (height, width) == (512, 2048) else None
     out = dict(images_per_s=world * batch * steps / dt, ms_per_step=dt / steps * 1e3, batch_per_gpu=batch, image=f"{height}x{width}", dtype=dtype,
-               steps=steps, includes="forward + MAELoss + backward" + (" + RCCL gradient all-reduce" if world > 1 else "") + " + fused AdamW step", loss=float(loss))
+               steps=steps, includes="forward + MAELoss + backward" + (" + RCCL gradient all-reduce" if world > 1 else "") + " + fused AdamW step", loss=float(loss.detach()))
     if flop_img:
         out["tflops_algorithmic"] = flop_img * world * batch * steps / dt / 1e12
     del mae, ddp, opt
