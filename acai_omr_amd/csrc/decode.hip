@@ -809,6 +809,194 @@ __global__ __launch_bounds__(256) void decode_attn_group_kernel(DAttnArgs a, int
     }
 }
 
+// ---- the same on the matrix cores (bf16, d_h padded to 64): the form that pays ---------------------------------------------------------
+// Up to 16 rollout rows of one image are the 16 columns of v_mfma_f32_16x16x32_bf16.  A wave owns 32-key tiles of the workgroup's chunk:
+//   S[key][g]  = K . Q^T      A = K rows, loaded from global memory straight in the A layout (lane = key, 16 B = 8 dims), B = Q^T in registers
+//   O^T[d][g] += V^T . P      B = P taken from the S accumulators as they stand (keys 4q+j of both 16-key halves = contraction slots 8q+j),
+//                             A = V^T read with ds_read_b64_tr_b16 from the wave's private 4 KB image of the V tile (no barrier in the loop)
+// so the K/V stream is read once per IMAGE and the per-key VALU work is the softmax of 8 scores per lane.  The running maximum of a query is
+// kept equal across the four lanes that share its column (two shuffles when it is raised, lazily); partials / tickets / merge as above.
+__global__ __launch_bounds__(256) void decode_attn_gmfma_kernel(DAttnArgs a, int group, int gtiles) {
+    typedef bf16_t TC;
+    typedef TileLayout<2, 64> TL;
+    constexpr int GT = 16, KT = 32, DHP = 64;
+    __shared__ __attribute__((aligned(16))) unsigned char vlds[4][KT * DHP * 2];
+    __shared__ float red[4][GT][2 + 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int split = blockIdx.x, h = blockIdx.y, img = blockIdx.z / gtiles, gt = blockIdx.z % gtiles;
+    const int row0 = img * group + gt * GT, ng = min(GT, group - gt * GT);
+    const int len = a.seq_len[row0], hstride = len * DHP;
+    const size_t base = (size_t)a.seq_off[row0] + (size_t)h * hstride;
+    const int c0 = split * a.chunk, c1 = min(len, c0 + a.chunk);
+    const bool fused_merge = a.tickets && a.out && a.nsplit > 1;
+    auto part_of = [&](int g) { return a.partial + (((size_t)(row0 + g) * a.H + h) * a.nsplit + split) * (DHP + 2); };
+    if (c0 >= len) {  // empty split: neutral elements
+        if (tid < DHP + 2)
+            for (int g = 0; g < ng; ++g) {
+                if (fused_merge) __hip_atomic_store(part_of(g) + tid, tid == 0 ? -1.0e30f : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else part_of(g)[tid] = tid == 0 ? -1.0e30f : 0.f;
+            }
+        if (!fused_merge) return;
+    }
+    const TC *Kp = reinterpret_cast<const TC *>(a.kc) + base;
+    const TC *Vp = reinterpret_cast<const TC *>(a.vc) + base;
+
+    // Q^T fragments: lane (g = r16, kq) holds dims db * 32 + kq * 8 + 0..7 of query row0 + g (bf16, as the reference's autocast SDPA input)
+    uint4 qb[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int d = db * 32 + kq * 8 + e;
+            t[e] = (r16 < ng && d < a.dh) ? a.q[(size_t)(row0 + r16) * a.ldq + h * a.dh + d] : 0.f;
+        }
+        qb[db] = make_uint4(pack_bf16(t[0], t[1]), pack_bf16(t[2], t[3]), pack_bf16(t[4], t[5]), pack_bf16(t[6], t[7]));
+    }
+    float m = -1.0e30f, l = 0.f;
+    f32x4 oacc[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned char *vimg = vlds[wave];
+    typedef __attribute__((ext_vector_type(4))) short s4;
+    typedef __attribute__((address_space(3))) s4 *lds_s4;
+
+    for (int key0 = c0 + wave * KT; key0 < c1; key0 += 4 * KT) {
+        uint4 kf[2][2], vv[4];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int key = key0 + sub * 16 + r16;
+#pragma unroll
+            for (int db = 0; db < 2; ++db) kf[sub][db] = key < c1 ? ld_nt16(Kp + (size_t)key * DHP + db * 32 + kq * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i, row = c >> 3, key = key0 + row;
+            vv[i] = key < c1 ? ld_nt16(Vp + (size_t)key * DHP + (c & 7) * 8) : make_uint4(0, 0, 0, 0);
+        }
+        f32x4 sc[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            sc[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                sc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[sub][db]), __builtin_bit_cast(bf16x8, qb[db]), sc[sub], 0, 0, 0);
+        }
+        // this lane: keys key0 + 16 sub + 4 kq + j of query r16
+        float tmax = -1.0e30f;
+        bool ok[2][4];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ok[sub][j] = key0 + sub * 16 + 4 * kq + j < c1;
+                sc[sub][j] *= a.scale_log2e;
+                if (ok[sub][j]) tmax = fmaxf(tmax, sc[sub][j]);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));   // equal on the four lanes of a query column
+        if (__ballot(tmax > m + 8.0f)) {
+            const float mn = fmaxf(m, tmax), al = fast_exp2(m - mn);
+            m = mn;
+            l *= al;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) oacc[d] *= al;
+        }
+        float p[2][4];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                p[sub][j] = ok[sub][j] ? fast_exp2(sc[sub][j] - m) : 0.f;
+                l += p[sub][j];
+            }
+        const uint4 pf = make_uint4(pack_bf16(p[0][0], p[0][1]), pack_bf16(p[0][2], p[0][3]), pack_bf16(p[1][0], p[1][1]), pack_bf16(p[1][2], p[1][3]));
+        // V tile -> this wave's LDS image (the previous tile's transposing reads were consumed by its MFMAs: same wave, in order)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i;
+            *reinterpret_cast<uint4 *>(vimg + TL::off(c >> 3, c & 7)) = vv[i];
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int vrow = 4 * kq + (r16 >> 2), vchunk = d * 2 + ((r16 & 3) >> 1), vsub = 8 * (r16 & 1);
+            union { s4 v[2]; uint4 u; } vf;
+            vf.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(vimg + TL::off(vrow, vchunk) + vsub));
+            vf.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(vimg + TL::off(vrow + 16, vchunk) + vsub));
+            oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf.u), __builtin_bit_cast(bf16x8, pf), oacc[d], 0, 0, 0);
+        }
+    }
+    // wave result: column g = r16; l summed over the four lanes of the column; O^T rows d = 16 dblk + 4 kq + j
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (kq == 0) {
+        red[wave][r16][0] = m;
+        red[wave][r16][1] = l;
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[wave][r16][2 + d * 16 + 4 * kq + j] = oacc[d][j];
+    __syncthreads();
+    if (tid < DHP + 2 && c0 < len) {
+        for (int g = 0; g < ng; ++g) {
+            const float M = fmaxf(fmaxf(red[0][g][0], red[1][g][0]), fmaxf(red[2][g][0], red[3][g][0]));
+            float v = 0.f, lsum = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float f = fast_exp2(red[w][g][0] - M);
+                v += red[w][g][tid] * f;
+                lsum += red[w][g][1] * f;
+            }
+            if (a.nsplit == 1 && a.out) {
+                const int d = tid - 2;
+                if (d >= 0 && d < a.dh) {
+                    float o = v / lsum;
+                    if (a.round_out) o = round_bf16(o);
+                    a.out[(size_t)(row0 + g) * a.ldo + h * a.dh + d] = o;
+                }
+            } else if (fused_merge) {
+                __hip_atomic_store(part_of(g) + tid, tid == 0 ? M : v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                part_of(g)[tid] = tid == 0 ? M : v;
+            }
+        }
+    }
+    if (fused_merge) {   // see decode_attn_kernel: write-through partials, one ticket per (first row of the tile, head)
+        __shared__ int s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            unsigned *cnt = a.tickets + (size_t)row0 * a.H + h;
+            const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = t == (unsigned)(a.nsplit - 1);
+            if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = last;
+        }
+        __syncthreads();
+        if (s_last && tid < DHP) {
+            for (int g = 0; g < ng; ++g) {
+                float *pp = a.partial + ((size_t)(row0 + g) * a.H + h) * a.nsplit * (DHP + 2);
+                auto ld = [&](int i) { return __hip_atomic_load(pp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+                float M = -1.0e30f;
+                for (int s2 = 0; s2 < a.nsplit; ++s2) M = fmaxf(M, ld(s2 * (DHP + 2)));
+                float ls = 0.f, o = 0.f;
+                for (int s2 = 0; s2 < a.nsplit; ++s2) {
+                    const float w = fast_exp2(ld(s2 * (DHP + 2)) - M);
+                    ls += ld(s2 * (DHP + 2) + 1) * w;
+                    o += ld(s2 * (DHP + 2) + 2 + tid) * w;
+                }
+                if (tid < a.dh) {
+                    float v = o / ls;
+                    if (a.round_out) v = round_bf16(v);
+                    a.out[(size_t)(row0 + g) * a.ldo + h * a.dh + tid] = v;
+                }
+            }
+        }
+    }
+}
+
 // one wave per (b, h): out[b, h*dh + d] = sum_s o_s[d] 2^(m_s - M) / sum_s l_s 2^(m_s - M)
 __global__ __launch_bounds__(64) void attn_combine_kernel(const float *partial, float *out, int ldo, int H, int dh, int dhp,
                                                           int nsplit, int round_out) {
@@ -986,7 +1174,13 @@ __global__ void advance_cache_kernel(int32_t *step) { step[1] = step[1] + 1; }
 // rollout groups: B rows = B / group images x group rows; the grouped kernel needs the in-launch merge (or a single split)
 template <typename TC>
 int launch_dattn_group(const DAttnArgs &a, int B, int group, hipStream_t st) {
-    constexpr int GT = 4;   // rows per workgroup: 8 costs 256+ VGPRs (one wave per SIMD) and ran slower than re-reading from L2
+    if (sizeof(TC) == 2 && a.dhp == 64) {   // matrix-core form: up to 16 rows per workgroup
+        const int gtm = cdiv(group, 16);
+        hipLaunchKernelGGL(decode_attn_gmfma_kernel, dim3(a.nsplit, a.H, (B / group) * gtm), dim3(256), 0, st, a, group, gtm);
+        ACAI_LAUNCH_CHECK("decode_attn_gmfma");
+        return 0;
+    }
+    constexpr int GT = 4;   // VALU form: 8 rows cost 256+ VGPRs (one wave per SIMD) and ran slower than re-reading from L2
     const int lpk = a.dhp * (int)sizeof(TC) / 16, gtiles = cdiv(group, GT);
     dim3 grid(a.nsplit, a.H, (B / group) * gtiles);
     if (lpk == 8) hipLaunchKernelGGL((decode_attn_group_kernel<TC, 8, GT>), grid, dim3(256), 0, st, a, group, gtiles);
@@ -1063,9 +1257,11 @@ int decode_core(const AcaiDecoder *d, const int64_t *tokens, hipStream_t st, boo
         // Measured (8 images x 8 rollouts, S = 4096, tools/bench_rollout.py): rows that ALIAS one stored K/V through the per-row kernel take
         // 3.25 ms/step (their re-reads hit L2 / Infinity Cache; 4.2 ms with 8 materialised copies); this VALU grouped kernel takes 3.7 ms with 4
         // rows per workgroup and 4.8 ms with 8 (256+ VGPRs, one wave per SIMD).  It is therefore opt-in (ACAI_DECODE_GROUP_KERNEL=1) until the
-        // score / PV products of a row tile move to the matrix cores.
-        static const bool group_kernel = getenv("ACAI_DECODE_GROUP_KERNEL") && atoi(getenv("ACAI_DECODE_GROUP_KERNEL")) != 0;
-        const int group = (group_kernel && cross && d->cross_group > 1 && B % d->cross_group == 0 && d->dhp * (int)sizeof(TW) >= 64) ? d->cross_group : 1;
+        // score / PV products of a row tile move to the matrix cores - which decode_attn_gmfma_kernel does for bf16 / d_h = 64 (default there).
+        static const int group_kernel = getenv("ACAI_DECODE_GROUP_KERNEL") ? atoi(getenv("ACAI_DECODE_GROUP_KERNEL")) : -1;   // -1 auto, 0 off, 1 on
+        const bool mfma_form = sizeof(TW) == 2 && d->dhp == 64;
+        const bool use_group = group_kernel < 0 ? mfma_form : group_kernel != 0;
+        const int group = (use_group && cross && d->cross_group > 1 && B % d->cross_group == 0 && d->dhp * (int)sizeof(TW) >= 64) ? d->cross_group : 1;
         if (a.nsplit == 1) {
             a.out = d->attn; a.ldo = E; a.round_out = rnd ? 1 : 0;
             return group > 1 ? launch_dattn_group<TW>(a, B, group, st) : launch_dattn<TW>(a, B, st);
