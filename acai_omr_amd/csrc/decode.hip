@@ -614,202 +614,11 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DAttnArgs a) {
     }
 }
 
-// ---- cross attention of a rollout GROUP (GRPO, models.py:883-891 / 988-1049) ---------------------------------------------------------
+// ---- cross attention of a rollout GROUP (GRPO, models.py:883-891 / 988-1049) on the matrix cores (bf16, d_h padded to 64) --------------
 // `group` consecutive decode rows share one image's cross K/V (the engine stores it once).  A workgroup owns (split, head, image, tile of
-// GT rows) and streams its K/V chunk ONCE for all GT queries: the HBM stream of a step no longer grows with the group size (the per-row
-// kernel re-read the same keys `group` times: 8 x 134 MB per layer for 8 rollouts x 8 images).  Per key a lane group forms GT dot products
-// and GT softmax/PV updates - VALU work comparable to the stream time at GT = 8, so the rescale of the running maximum is lazy (only when
-// some score exceeds it by 2^8; p <= 256 otherwise).  Partials, tickets and the in-launch merge are those of decode_attn_kernel, per row.
-template <typename TC, int LPK, int GT>
-__global__ __launch_bounds__(256) void decode_attn_group_kernel(DAttnArgs a, int group, int gtiles) {
-    constexpr int EPC = 16 / sizeof(TC), KPW = 64 / LPK, U = 4;
-    __shared__ float red[4][GT][2 + 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kq = lane % LPK, kg = lane / LPK;
-    const int split = blockIdx.x, h = blockIdx.y, img = blockIdx.z / gtiles, gt = blockIdx.z % gtiles;
-    const int row0 = img * group + gt * GT, ng = min(GT, group - gt * GT);
-    const int len = a.seq_len[row0], hstride = len * a.dhp;
-    const size_t base = (size_t)a.seq_off[row0] + (size_t)h * hstride;
-    const int c0 = split * a.chunk, c1 = min(len, c0 + a.chunk);
-    const bool fused_merge = a.tickets && a.out && a.nsplit > 1;
-    auto part_of = [&](int g) { return a.partial + (((size_t)(row0 + g) * a.H + h) * a.nsplit + split) * (a.dhp + 2); };
-    if (c0 >= len) {  // empty split: neutral elements
-        if (tid < a.dhp + 2)
-            for (int g = 0; g < ng; ++g) {
-                if (fused_merge) __hip_atomic_store(part_of(g) + tid, tid == 0 ? -1.0e30f : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else part_of(g)[tid] = tid == 0 ? -1.0e30f : 0.f;
-            }
-        if (!fused_merge) return;
-    }
-    const TC *Kp = reinterpret_cast<const TC *>(a.kc) + base;
-    const TC *Vp = reinterpret_cast<const TC *>(a.vc) + base;
-
-    float qf[GT][EPC], m[GT], l[GT], acc[GT][EPC];
-#pragma unroll
-    for (int g = 0; g < GT; ++g) {
-        m[g] = -1.0e30f;
-        l[g] = 0.f;
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            const int d = kq * EPC + e;
-            qf[g][e] = (g < ng && d < a.dh) ? a.q[(size_t)(row0 + g) * a.ldq + h * a.dh + d] * a.scale_log2e : 0.f;   // scores in the log2 domain
-            acc[g][e] = 0.f;
-        }
-    }
-    for (int key0 = c0 + wave * KPW + kg; key0 < c1; key0 += 4 * KPW * U) {
-        uint4 kk[U], vv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int key = key0 + u * 4 * KPW;
-            kk[u] = vv[u] = make_uint4(0, 0, 0, 0);
-            if (key < c1) {
-                kk[u] = ld_nt16(Kp + (size_t)key * a.dhp + kq * EPC);
-                vv[u] = ld_nt16(Vp + (size_t)key * a.dhp + kq * EPC);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int key = key0 + u * 4 * KPW;
-            float kf[EPC], vf[EPC];
-            if constexpr (sizeof(TC) == 2) {
-                const uint32_t kw[4] = {kk[u].x, kk[u].y, kk[u].z, kk[u].w}, vw[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    kf[2 * e] = __uint_as_float(kw[e] << 16);
-                    kf[2 * e + 1] = __uint_as_float(kw[e] & 0xffff0000u);
-                    vf[2 * e] = __uint_as_float(vw[e] << 16);
-                    vf[2 * e + 1] = __uint_as_float(vw[e] & 0xffff0000u);
-                }
-            } else {
-                const f32x4 k4 = __builtin_bit_cast(f32x4, kk[u]), v4 = __builtin_bit_cast(f32x4, vv[u]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    kf[e] = k4[e];
-                    vf[e] = v4[e];
-                }
-            }
-            float sc[GT];
-#pragma unroll
-            for (int g = 0; g < GT; ++g) {
-                float t = 0.f;
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) t = fmaf(qf[g][e], kf[e], t);
-                sc[g] = t;
-            }
-#pragma unroll
-            for (int o = 1; o < LPK; o <<= 1)
-#pragma unroll
-                for (int g = 0; g < GT; ++g) sc[g] += __shfl_xor(sc[g], o);
-            const bool valid = key < c1;   // uniform inside a lane group
-            bool raise = false;
-#pragma unroll
-            for (int g = 0; g < GT; ++g) raise |= valid && sc[g] > m[g] + 8.0f;
-            if (__ballot(raise)) {         // wave-uniform: rare after the first keys
-#pragma unroll
-                for (int g = 0; g < GT; ++g) {
-                    const float mn = valid ? fmaxf(m[g], sc[g]) : m[g], al = fast_exp2(m[g] - mn);
-                    m[g] = mn;
-                    l[g] *= al;
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) acc[g][e] *= al;
-                }
-            }
-            if (valid) {
-#pragma unroll
-                for (int g = 0; g < GT; ++g) {
-                    const float p = fast_exp2(sc[g] - m[g]);
-                    l[g] += p;
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) acc[g][e] = fmaf(p, vf[e], acc[g][e]);
-                }
-            }
-        }
-    }
-    // merge the KPW lane groups of this wave (lanes with equal kq), per query
-#pragma unroll
-    for (int g = 0; g < GT; ++g) {
-        float mw = m[g];
-#pragma unroll
-        for (int o = LPK; o < 64; o <<= 1) mw = fmaxf(mw, __shfl_xor(mw, o));
-        const float f = fast_exp2(m[g] - mw);
-        float lg = l[g] * f;
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) acc[g][e] *= f;
-#pragma unroll
-        for (int o = LPK; o < 64; o <<= 1) {
-            lg += __shfl_xor(lg, o);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) acc[g][e] += __shfl_xor(acc[g][e], o);
-        }
-        if (kg == 0) {
-            if (kq == 0) {
-                red[wave][g][0] = mw;
-                red[wave][g][1] = lg;
-            }
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) red[wave][g][2 + kq * EPC + e] = acc[g][e];
-        }
-    }
-    __syncthreads();
-    if (tid < a.dhp + 2 && c0 < len) {
-        for (int g = 0; g < ng; ++g) {
-            const float M = fmaxf(fmaxf(red[0][g][0], red[1][g][0]), fmaxf(red[2][g][0], red[3][g][0]));
-            float v = 0.f, lsum = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const float f = fast_exp2(red[w][g][0] - M);
-                v += red[w][g][tid] * f;
-                lsum += red[w][g][1] * f;
-            }
-            if (a.nsplit == 1 && a.out) {
-                const int d = tid - 2;
-                if (d >= 0 && d < a.dh) {
-                    float o = v / lsum;
-                    if (a.round_out) o = round_bf16(o);
-                    a.out[(size_t)(row0 + g) * a.ldo + h * a.dh + d] = o;
-                }
-            } else if (fused_merge) {
-                __hip_atomic_store(part_of(g) + tid, tid == 0 ? M : v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                part_of(g)[tid] = tid == 0 ? M : v;
-            }
-        }
-    }
-    if (fused_merge) {   // see decode_attn_kernel: write-through partials, one ticket per (first row of the tile, head)
-        __shared__ int s_last;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            unsigned *cnt = a.tickets + (size_t)row0 * a.H + h;
-            const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = t == (unsigned)(a.nsplit - 1);
-            if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = last;
-        }
-        __syncthreads();
-        if (s_last && tid < a.dhp) {
-            for (int g = 0; g < ng; ++g) {
-                float *p = a.partial + ((size_t)(row0 + g) * a.H + h) * a.nsplit * (a.dhp + 2);
-                auto ld = [&](int i) { return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-                float M = -1.0e30f;
-                for (int s2 = 0; s2 < a.nsplit; ++s2) M = fmaxf(M, ld(s2 * (a.dhp + 2)));
-                float ls = 0.f, o = 0.f;
-                for (int s2 = 0; s2 < a.nsplit; ++s2) {
-                    const float w = fast_exp2(ld(s2 * (a.dhp + 2)) - M);
-                    ls += ld(s2 * (a.dhp + 2) + 1) * w;
-                    o += ld(s2 * (a.dhp + 2) + 2 + tid) * w;
-                }
-                if (tid < a.dh) {
-                    float v = o / ls;
-                    if (a.round_out) v = round_bf16(v);
-                    a.out[(size_t)(row0 + g) * a.ldo + h * a.dh + tid] = v;
-                }
-            }
-        }
-    }
-}
-
-// ---- the same on the matrix cores (bf16, d_h padded to 64): the form that pays ---------------------------------------------------------
+// 16 rows) and streams its K/V chunk ONCE for all of them: the HBM stream of a step no longer grows with the group size.  (A VALU form -
+// GT dot products and softmax updates per key and lane group - was built first and measured SLOWER than letting the rows alias the
+// stored K/V through the per-row kernel: 3.7-4.8 ms against 3.25 ms per step at 8 x 8; it is gone.)
 // Up to 16 rollout rows of one image are the 16 columns of v_mfma_f32_16x16x32_bf16.  A wave owns 32-key tiles of the workgroup's chunk:
 //   S[key][g]  = K . Q^T      A = K rows, loaded from global memory straight in the A layout (lane = key, 16 B = 8 dims), B = Q^T in registers
 //   O^T[d][g] += V^T . P      B = P taken from the S accumulators as they stand (keys 4q+j of both 16-key halves = contraction slots 8q+j),
@@ -1171,23 +980,11 @@ __global__ __launch_bounds__(64) void sample_bookkeeping_kernel(int B, int32_t *
 
 __global__ void advance_cache_kernel(int32_t *step) { step[1] = step[1] + 1; }
 
-// rollout groups: B rows = B / group images x group rows; the grouped kernel needs the in-launch merge (or a single split)
-template <typename TC>
-int launch_dattn_group(const DAttnArgs &a, int B, int group, hipStream_t st) {
-    if (sizeof(TC) == 2 && a.dhp == 64) {   // matrix-core form: up to 16 rows per workgroup
-        const int gtm = cdiv(group, 16);
-        hipLaunchKernelGGL(decode_attn_gmfma_kernel, dim3(a.nsplit, a.H, (B / group) * gtm), dim3(256), 0, st, a, group, gtm);
-        ACAI_LAUNCH_CHECK("decode_attn_gmfma");
-        return 0;
-    }
-    constexpr int GT = 4;   // VALU form: 8 rows cost 256+ VGPRs (one wave per SIMD) and ran slower than re-reading from L2
-    const int lpk = a.dhp * (int)sizeof(TC) / 16, gtiles = cdiv(group, GT);
-    dim3 grid(a.nsplit, a.H, (B / group) * gtiles);
-    if (lpk == 8) hipLaunchKernelGGL((decode_attn_group_kernel<TC, 8, GT>), grid, dim3(256), 0, st, a, group, gtiles);
-    else if (lpk == 4) hipLaunchKernelGGL((decode_attn_group_kernel<TC, 4, GT>), grid, dim3(256), 0, st, a, group, gtiles);
-    else if (lpk == 16) hipLaunchKernelGGL((decode_attn_group_kernel<TC, 16, GT>), grid, dim3(256), 0, st, a, group, gtiles);
-    else return acai_set_err(-1, "decode_attn (group): dhp=%d unsupported", a.dhp);
-    ACAI_LAUNCH_CHECK("decode_attn_group");
+// rollout groups: B rows = B / group images x group rows (bf16, dhp = 64; needs the in-launch merge or a single split)
+inline int launch_dattn_group(const DAttnArgs &a, int B, int group, hipStream_t st) {
+    const int gtm = cdiv(group, 16);
+    hipLaunchKernelGGL(decode_attn_gmfma_kernel, dim3(a.nsplit, a.H, (B / group) * gtm), dim3(256), 0, st, a, group, gtm);
+    ACAI_LAUNCH_CHECK("decode_attn_gmfma");
     return 0;
 }
 
@@ -1254,21 +1051,17 @@ int decode_core(const AcaiDecoder *d, const int64_t *tokens, hipStream_t st, boo
         } else {
             a.step = d->step; a.chunk = d->self_chunk; a.nsplit = d->self_nsplit;
         }
-        // Measured (8 images x 8 rollouts, S = 4096, tools/bench_rollout.py): rows that ALIAS one stored K/V through the per-row kernel take
-        // 3.25 ms/step (their re-reads hit L2 / Infinity Cache; 4.2 ms with 8 materialised copies); this VALU grouped kernel takes 3.7 ms with 4
-        // rows per workgroup and 4.8 ms with 8 (256+ VGPRs, one wave per SIMD).  It is therefore opt-in (ACAI_DECODE_GROUP_KERNEL=1) until the
-        // score / PV products of a row tile move to the matrix cores - which decode_attn_gmfma_kernel does for bf16 / d_h = 64 (default there).
-        static const int group_kernel = getenv("ACAI_DECODE_GROUP_KERNEL") ? atoi(getenv("ACAI_DECODE_GROUP_KERNEL")) : -1;   // -1 auto, 0 off, 1 on
-        const bool mfma_form = sizeof(TW) == 2 && d->dhp == 64;
-        const bool use_group = group_kernel < 0 ? mfma_form : group_kernel != 0;
-        const int group = (use_group && cross && d->cross_group > 1 && B % d->cross_group == 0 && d->dhp * (int)sizeof(TW) >= 64) ? d->cross_group : 1;
+        // rollout groups (bf16, d_h padded to 64): one K/V stream per image through the matrix-core kernel; otherwise the rows simply alias
+        // the stored K/V through the per-row kernel (ACAI_DECODE_GROUP_KERNEL=0 forces that form: A/B aid)
+        static const bool no_group = getenv("ACAI_DECODE_GROUP_KERNEL") && atoi(getenv("ACAI_DECODE_GROUP_KERNEL")) == 0;
+        const int group = (!no_group && sizeof(TW) == 2 && d->dhp == 64 && cross && d->cross_group > 1 && B % d->cross_group == 0) ? d->cross_group : 1;
         if (a.nsplit == 1) {
             a.out = d->attn; a.ldo = E; a.round_out = rnd ? 1 : 0;
-            return group > 1 ? launch_dattn_group<TW>(a, B, group, st) : launch_dattn<TW>(a, B, st);
+            return group > 1 ? launch_dattn_group(a, B, group, st) : launch_dattn<TW>(a, B, st);
         }
         if (d->tickets) {
             a.out = d->attn; a.ldo = E; a.round_out = rnd ? 1 : 0; a.tickets = d->tickets;
-            return group > 1 ? launch_dattn_group<TW>(a, B, group, st) : launch_dattn<TW>(a, B, st);
+            return group > 1 ? launch_dattn_group(a, B, group, st) : launch_dattn<TW>(a, B, st);
         }
         int r = launch_dattn<TW>(a, B, st);
         if (r) return r;
