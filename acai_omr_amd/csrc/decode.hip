@@ -179,7 +179,9 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
     float *red = reinterpret_cast<float *>(smem);              // [NW][256] floats
     unsigned char *xs = smem + NW * 1024;                      // [rows][pitch] bf16 activation image
 
-    for (int bt = 0; bt < a.B; bt += 16) {
+    // batch tiles of 16 rows: one per workgroup along grid.y (B > 16: GRPO rollouts, max_batch_size = 32 inference) - the tiles of a weight
+    // row block re-read its weights from L2 instead of queueing four latency chains inside one workgroup (64 rows: 24 -> 17 us per launch)
+    for (int bt = blockIdx.y * 16; bt < a.B; bt += 16 * gridDim.y) {
         const int nb = min(16, a.B - bt);
         // 1. first batch of weight fragments in flight
         uint4 wf[8];
@@ -401,7 +403,7 @@ int launch_skinny(const SkinnyArgs &a, hipStream_t st) {
             static const int ntm = getenv("ACAI_SKINNY_NT") ? atoi(getenv("ACAI_SKINNY_NT")) : 1;
             if (ntm == 0 || (ntm == 2 && (size_t)a.N * a.K * 2 < (8u << 20))) b.ablate |= 8;
             b.rows_per_block = rpb ? rpb : (a.N >= 2560 ? 16 : (a.N >= 1600 ? 8 : 4));
-            const dim3 grid(cdiv(a.N, b.rows_per_block));
+            const dim3 grid(cdiv(a.N, b.rows_per_block), cdiv(a.B, 16));
             if (wide)
                 hipLaunchKernelGGL((skinny_mfma_kernel<true, 1, 16>), grid, dim3(1024), lds, st, b);
             else if (a.x_bf16)
