@@ -403,7 +403,8 @@ int launch_skinny(const SkinnyArgs &a, hipStream_t st) {
             static const int ntm = getenv("ACAI_SKINNY_NT") ? atoi(getenv("ACAI_SKINNY_NT")) : 1;
             if (ntm == 0 || (ntm == 2 && (size_t)a.N * a.K * 2 < (8u << 20))) b.ablate |= 8;
             b.rows_per_block = rpb ? rpb : (a.N >= 2560 ? 16 : (a.N >= 1600 ? 8 : 4));
-            const dim3 grid(cdiv(a.N, b.rows_per_block), cdiv(a.B, 16));
+            // (the K = 4096 form holds a 131 KB activation image: one workgroup per CU, so its batch tiles stay a loop inside the workgroup)
+            const dim3 grid(cdiv(a.N, b.rows_per_block), wide ? 1 : cdiv(a.B, 16));
             if (wide)
                 hipLaunchKernelGGL((skinny_mfma_kernel<true, 1, 16>), grid, dim3(1024), lds, st, b);
             else if (a.x_bf16)
