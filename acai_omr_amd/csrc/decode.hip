@@ -449,7 +449,7 @@ struct DAttnArgs {
 // rocprof reports them as separate kernels.
 template <typename TC, int LPK, bool RAGGED>
 __global__ __launch_bounds__(256) void decode_attn_kernel(DAttnArgs a) {
-    constexpr int EPC = 16 / sizeof(TC), KPW = 64 / LPK, U = 4;
+    constexpr int EPC = 16 / sizeof(TC), KPW = 64 / LPK, U = 2;
     __shared__ float red[4][2 + 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane % LPK, kg = lane / LPK;
@@ -488,18 +488,30 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DAttnArgs a) {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
 
+    // software pipeline: the U key groups of iteration i+1 are requested before iteration i is computed (a wave that computes has no load
+    // in flight otherwise: PMC showed the VALU busy a third of the time and the waves waiting on memory for half of it)
+    uint4 kn[U], vn[U];
+    auto request = [&](int key0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int key = key0 + u * 4 * KPW;
+            kn[u] = vn[u] = make_uint4(0, 0, 0, 0);
+            if (key < c1) {
+                // every K/V byte is read exactly once per step: non-temporal loads (streaming cache policy)
+                kn[u] = ld_nt16(Kp + (size_t)key * a.dhp + kq * EPC);
+                vn[u] = ld_nt16(Vp + (size_t)key * a.dhp + kq * EPC);
+            }
+        }
+    };
+    request(c0 + wave * KPW + kg);
     for (int key0 = c0 + wave * KPW + kg; key0 < c1; key0 += 4 * KPW * U) {
         uint4 kk[U], vv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int key = key0 + u * 4 * KPW;
-            kk[u] = vv[u] = make_uint4(0, 0, 0, 0);
-            if (key < c1) {
-                // every K/V byte is read exactly once per step: non-temporal loads (streaming cache policy)
-                kk[u] = ld_nt16(Kp + (size_t)key * a.dhp + kq * EPC);
-                vv[u] = ld_nt16(Vp + (size_t)key * a.dhp + kq * EPC);
-            }
+            kk[u] = kn[u];
+            vv[u] = vn[u];
         }
+        if (key0 + 4 * KPW * U < c1) request(key0 + 4 * KPW * U);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int key = key0 + u * 4 * KPW;
