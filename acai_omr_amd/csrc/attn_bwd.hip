@@ -65,6 +65,31 @@ __device__ __forceinline__ void mma_rows(f32x16 &acc, const unsigned char *tile,
     }
 }
 
+// two independent products that share their loop structure (S and dP): the MFMAs alternate between the two accumulators, so no link of a
+// dependent chain waits out the full MFMA latency
+template <typename T, int DHP, int NS>
+__device__ __forceinline__ void mma_rows2(f32x16 &acc0, const unsigned char *tile0, const uint4 (&bf0)[NS], f32x16 &acc1, const unsigned char *tile1,
+                                          const uint4 (&bf1)[NS], int r0, int lr, int lh) {
+    typedef TileLayout<sizeof(T), DHP> TL;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int o = TL::off(r0 + lr, 2 * s + lh);
+        const uint4 a0 = *reinterpret_cast<const uint4 *>(tile0 + o), a1 = *reinterpret_cast<const uint4 *>(tile1 + o);
+        if constexpr (sizeof(T) == 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bf0[s]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bf1[s]), acc1, 0, 0, 0);
+        } else {
+            const f32x4 x0 = __builtin_bit_cast(f32x4, a0), y0 = __builtin_bit_cast(f32x4, bf0[s]);
+            const f32x4 x1 = __builtin_bit_cast(f32x4, a1), y1 = __builtin_bit_cast(f32x4, bf1[s]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], y0[e], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], y1[e], acc1, 0, 0, 0);
+            }
+        }
+    }
+}
+
 // acc[c][lane] += tile^T . X: `tile` is a natural [row][col] LDS image (pitch bytes); the 32 contraction rows start at row r0,
 // the 32 output rows are its columns c0..c0+31; X is a 32x32 accumulator tile whose register rows are the contraction rows.
 // bf16: two 4-row x 16-col transposing reads (ds_read_b64_tr_b16) build the A fragment whose element j is contraction row
@@ -238,8 +263,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                 sacc[e] = 0.f;
                 dpacc[e] = DROP ? 0.f : -dlt;
             }
-            mma_rows<T, DHP, NS>(sacc, ldsK, kb * 32, lr, lh, qf);     // S^T[key][q]
-            mma_rows<T, DHP, NS>(dpacc, ldsV, kb * 32, lr, lh, dof);   // dP^T[key][q] (- delta)
+            mma_rows2<T, DHP, NS>(sacc, ldsK, qf, dpacc, ldsV, dof, kb * 32, lr, lh);   // S^T[key][q] and dP^T[key][q] (- delta)
             if constexpr (DROP) {  // dP = mask/(1-p) o (dO V^T)
                 const uint32_t rrow = (uint32_t)(h * a.total_q + q_start + my_q);
 #pragma unroll
@@ -363,8 +387,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) 
                 sacc[e] = 0.f;
                 dpacc[e] = DROP ? 0.f : -dlt4[e >> 2][e & 3];
             }
-            mma_rows<T, DHP, NS>(sacc, ldsQ, qb * 32, lr, lh, kf);      // S[q][key]
-            mma_rows<T, DHP, NS>(dpacc, ldsDO, qb * 32, lr, lh, vf);    // dP[q][key] (- delta)
+            mma_rows2<T, DHP, NS>(sacc, ldsQ, kf, dpacc, ldsDO, vf, qb * 32, lr, lh);   // S[q][key] and dP[q][key] (- delta)
             // interior: every query of the tile exists, every key of the WAVE exists and (causal) lies at or before the tile's first query
             const bool interior = (qt + 1) * TT <= lq && k0 + wave * 32 + 32 <= lk && (!a.causal || k0 + wave * 32 + 31 <= qt * TT + qb * 32);
             if (DROP) {  // keep mask of (query row, my key): dP is masked, and so is the P that multiplies dO for dV

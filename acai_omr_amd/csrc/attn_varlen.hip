@@ -156,11 +156,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         // ---- S^T = K . Q^T : two 32-key blocks ---------------------------------------------------------
         f32x16 sacc[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
+        // d-slice outer, key block inner: consecutive MFMAs alternate between the two accumulators (a chain of NS dependent MFMAs on
+        // one accumulator waits out the full MFMA latency at every link)
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
                 const uint4 kf = *reinterpret_cast<const uint4 *>(ldsK + TL::off(kb * 32 + lr, 2 * s + lh));
                 if constexpr (ES == 2) {
                     sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
