@@ -97,3 +97,33 @@ def test_host_bookkeeping_kats():
         dec.prepare_caches(torch.zeros(1, 2, 8))
     with pytest.raises(ValueError):
         dec.forward(torch.zeros(1, 9, dtype=torch.long), torch.zeros(1, 2, 8), None, None)
+
+
+def test_host_helpers_stringify_and_schedules():
+    """stringify_lmx_seq (utils.py:194-202) and the warm-up + cosine schedules (utils.py:204-222) drive FusedAdamW's param groups exactly as
+    they drive torch.optim.AdamW's (no step() is taken here: that needs the GPU)."""
+    import warnings
+    import torch
+    from acai_omr_amd.optim import FusedAdamW
+    from acai_omr_amd.utils import cosine_anneal_with_warmup, ragged_collate_fn, stepwise_cosine_anneal_with_warmup, stringify_lmx_seq
+    vocab = {0: "<bos>", 1: "<pad>", 2: "<eos>", 3: "measure", 4: "key:fifths:-7", 19: "time"}
+    assert stringify_lmx_seq(torch.tensor([0, 3, 4, 19, 2]), vocab) == "measure key:fifths:-7 time"
+    assert stringify_lmx_seq(torch.tensor([0, 3, 4]), vocab) == "measure key:fifths:-7"      # truncated: no <eos>
+    assert ragged_collate_fn([(1, 2), (3, 4)]) == [(1, 2), (3, 4)]
+
+    def lrs(opt_cls, make):
+        ps = [torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2))]
+        opt = opt_cls([dict(params=ps[:1], lr=1e-3), dict(params=ps[1:], lr=1.5e-4)], betas=(0.9, 0.95), weight_decay=0.05)
+        sch = make(opt)
+        out = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for _ in range(12):
+                out.append([g["lr"] for g in opt.param_groups])
+                sch.step()
+        return out
+
+    for make in (lambda o: cosine_anneal_with_warmup(o, 2, 10, 1e-6), lambda o: cosine_anneal_with_warmup(o, 1, 3, 1e-6, num_train_batches=4),
+                 lambda o: stepwise_cosine_anneal_with_warmup(o, 3, 2, 1e-6, 6)):
+        a, b = lrs(torch.optim.AdamW, make), lrs(FusedAdamW, make)
+        assert a == b and a[0][0] == 1e-3 * 5e-3 and max(x[0] for x in a) <= 1e-3 + 1e-12
