@@ -11,6 +11,7 @@ Precision ("fp32" | "bf16") follows the reference plumbing: fp32 = outside autoc
 torch.autocast(bfloat16) does to linear / SDPA (bf16 operands and outputs, fp32 accumulate, fp32 residual + LayerNorm).
 """
 import ctypes
+import os
 
 import torch
 
@@ -135,7 +136,7 @@ class DecodeEngine:
 
     # keys per cross-attention workgroup (split over the memory, merged in the launch).  1024 (4 splits of S = 4096, 512 workgroups) measured
     # +2.8 % tokens/s over 512 on the same box; 256 and 2048 are slower.  ACAI_CROSS_CHUNK overrides (A/B aid).
-    CROSS_CHUNK = int(__import__("os").environ.get("ACAI_CROSS_CHUNK", "1024"))
+    CROSS_CHUNK = int(os.environ.get("ACAI_CROSS_CHUNK", "1024"))
 
     def __init__(self, blocks, omr, max_batch_size, max_len, prec, device):
         self.blocks = blocks        # CachedTransformerDecoder mirror (layers, norm): parameters are read from it
