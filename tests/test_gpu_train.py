@@ -390,3 +390,80 @@ def test_scatter_add_rows_shared_row(dev):
     b = ops.scatter_add_rows(src, idx.to(dev), torch.zeros(table, dim, device=dev))
     assert torch.allclose(a.cpu(), ref, atol=2e-3, rtol=1e-4) and torch.allclose(b.cpu(), ref, atol=2e-3, rtol=1e-4)
     assert torch.equal(a[:900], b[:900])
+
+
+def test_full_size_mae_step_vs_oracle(dev):
+    """The FULL-SIZE MAE (ViT-B encoder 768/12/3072 x 12, decoder 512/16/3072 x 8; pre_train.py:156-159) on a small ragged batch: forward,
+    MAELoss and the gradients of the fp32 training step against autograd through the CPU oracle on the same weights and injected noise -
+    the golden fixtures use reduced widths, this runs the kernels at the real ones (d_h = 64 and 32, LayerNorm 768 / 512, every GEMM shape)."""
+    import oracle.vitomr_oracle as O
+    from acai_omr_amd.config import MASK_RATIO, PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH
+    from acai_omr_amd.models.models import MAE, MAELoss
+    torch.manual_seed(0)
+    mae = MAE(MASK_RATIO, PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH)
+    g = torch.Generator().manual_seed(5)
+    imgs = [torch.rand(1, 128, 256, generator=g), torch.rand(1, 256, 384, generator=g)]
+    noises = [torch.rand((im.shape[-2] // PATCH_SIZE) * (im.shape[-1] // PATCH_SIZE), generator=g) for im in imgs]
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in mae.state_dict().items()}
+    torch.set_num_threads(8)
+    pred_o, lm_o, tgt_o, lens = O.mae_forward(list(zip(imgs, imgs)), noises, sd, PATCH_SIZE, MASK_RATIO, 12, 16, prec="fp32")
+    loss_o = O.mae_loss(pred_o, lm_o, tgt_o)
+    loss_o.backward()
+    mae = mae.to(dev).train()
+    pred, loss_mask, target = mae([(im.to(dev), im.to(dev)) for im in imgs], noises=noises)
+    o = 0
+    for b, n in enumerate(lens):
+        assert md(pred[b, :n].cpu(), pred_o[o:o + n].detach()) < 1e-3
+        assert torch.equal(loss_mask[b, :n].cpu(), lm_o[o:o + n]) and md(target[b, :n].cpu(), tgt_o[o:o + n]) < 1e-5
+        o += n
+    loss = MAELoss()(pred, loss_mask, target)
+    assert abs(float(loss.detach()) - float(loss_o.detach())) < 1e-4
+    loss.backward()
+    params = dict(mae.named_parameters())
+    for name in ("mask_token", "decoder_pos_embedding", "decoder_unembed.weight", "decoder_embed.bias", "encoder.pos_embedding", "encoder.projection.weight",
+                 "encoder.encoder_blocks.layers.0.self_attn.in_proj_weight", "encoder.encoder_blocks.layers.11.linear2.bias",
+                 "decoder.decoder_blocks.layers.0.linear1.weight", "decoder.decoder_blocks.layers.7.norm2.weight"):
+        gref = sd[name].grad
+        assert gref is not None, name
+        assert md(params[name].grad, gref) < 3e-4 * max(1.0, float(gref.abs().max())), name
+
+
+def test_full_size_teacher_forced_step_vs_oracle(dev):
+    """The FULL-SIZE TeacherForcedViTOMR (FineTuneOMREncoder 768 x 12, head 4096, OMRDecoder 1024/16/4096 x 12, V = 227;
+    omr_teacher_force_train.py:265-284) on two small systems: logits, OMRCELoss and gradients of the fp32 step against autograd through the
+    CPU oracle on the same weights."""
+    import oracle.vitomr_oracle as O
+    from acai_omr_amd.config import ENCODER_FINE_TUNE_DEPTH, MAX_LMX_SEQ_LEN, NUM_DECODER_LAYERS, PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH
+    from acai_omr_amd.models.models import FineTuneOMREncoder, OMRCELoss, OMRDecoder, TeacherForcedViTOMR
+    torch.manual_seed(0)
+    enc = FineTuneOMREncoder(PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH, ENCODER_FINE_TUNE_DEPTH, transformer_dropout=0.0)
+    dec = OMRDecoder(MAX_LMX_SEQ_LEN, VOCAB, num_layers=NUM_DECODER_LAYERS, transformer_dropout=0.0)
+    m = TeacherForcedViTOMR(enc, None, dec, transition_head_dropout=0.0)
+    g = torch.Generator().manual_seed(6)
+    imgs = [torch.rand(1, 64, 256, generator=g), torch.rand(1, 128, 192, generator=g)]
+    lmx = [torch.cat([torch.tensor([0]), torch.randint(3, 227, (n,), generator=g), torch.tensor([2])]) for n in (17, 9)]
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in m.state_dict().items()}
+    torch.set_num_threads(8)
+    pred_o, tgt_o = O.teacher_forced_forward(list(zip(imgs, lmx)), sd, 12, 16, PATCH_SIZE, "fp32")
+    loss_o = O.ce_loss(pred_o, tgt_o, 1)
+    loss_o.backward()
+    m = m.to(dev).train()
+    pred, tgt = m([(im.to(dev), sq.to(dev)) for im, sq in zip(imgs, lmx)])
+    assert torch.equal(tgt.cpu(), tgt_o)
+    valid = tgt_o != 1
+    assert md(pred.cpu()[valid], pred_o.detach()[valid]) < 1e-3
+    loss = OMRCELoss(m.decoder.pad_idx)(pred, tgt)
+    assert abs(float(loss.detach()) - float(loss_o.detach())) < 1e-4
+    loss.backward()
+    params = dict(m.named_parameters())
+    checked = 0
+    for name in ("decoder.unembed.weight", "decoder.vocab_embedding.weight", "decoder.pos_embedding", "decoder.decoder_blocks.layers.0.multihead_attn.in_proj_weight",
+                 "decoder.decoder_blocks.layers.11.linear1.bias", "decoder.decoder_blocks.layers.5.norm3.weight", "transition_head.0.weight", "transition_head.3.bias",
+                 "encoder.fine_tune_blocks.layers.0.self_attn.out_proj.weight", "encoder.fine_tune_blocks.norm.bias"):
+        if name not in params or not params[name].requires_grad:
+            continue
+        gref = sd[name].grad
+        assert gref is not None, name
+        assert md(params[name].grad, gref) < 3e-4 * max(1.0, float(gref.abs().max())), name
+        checked += 1
+    assert checked >= 8
