@@ -434,3 +434,31 @@ def test_grpo_rollout_policy_sampling(dev, cache_dtype, name):
             probs = torch.zeros_like(counts)
             probs[top.indices] = torch.softmax(top.values.double(), 0)
             assert float((counts / counts.sum() - probs).abs().max()) < 0.12 and float(counts[probs == 0].sum()) == 0
+
+
+def test_full_size_encoder_and_head_vs_oracle(dev):
+    """The FULL-SIZE encoder (768 x 12 heads x 12 layers, 60 x 200 PE grid) and transition head on a ragged pair of systems, fp32 as
+    `inference()` runs them (vitomr_inference.py:63,81), against the CPU oracle: the fixtures use reduced widths."""
+    import oracle.vitomr_oracle as O
+    from acai_omr_amd.config import ENCODER_FINE_TUNE_DEPTH, MAX_LMX_SEQ_LEN, NUM_DECODER_LAYERS, PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH
+    from acai_omr_amd.models.models import FineTuneOMREncoder, OMRDecoder, TeacherForcedViTOMR
+    torch.manual_seed(1)
+    enc = FineTuneOMREncoder(PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH, ENCODER_FINE_TUNE_DEPTH)
+    dec = OMRDecoder(MAX_LMX_SEQ_LEN, VOCAB, num_layers=NUM_DECODER_LAYERS)
+    m = TeacherForcedViTOMR(enc, None, dec)
+    g = torch.Generator().manual_seed(2)
+    imgs = [torch.rand(1, 256, 1024, generator=g), torch.rand(1, 128, 640, generator=g)]
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    torch.set_num_threads(8)
+    lat_o, lens = O.encoder_forward(imgs, sd, "encoder.", PATCH_SIZE, 12, "omr_ft", "fp32")
+    mem_o = O.transition_head(lat_o, sd, "fp32")
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        lat, mask = m.encoder([im.to(dev) for im in imgs])
+        mem = m.transition_head(lat)
+    assert (~mask).sum(1).tolist() == lens
+    o = 0
+    for b, n in enumerate(lens):
+        assert md(lat[b, :n], lat_o[o:o + n]) < 1e-3, b
+        assert md(mem[b, :n], mem_o[o:o + n]) < 1e-3, b
+        o += n
