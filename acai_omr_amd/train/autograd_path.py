@@ -114,18 +114,39 @@ class LinearFn(Function):
         return dx, dW, db, dres, None, None, None
 
 
+def _compute_copy(x32, prec):
+    """The fp32 stream in the compute dtype: the bf16 copy its producing LayerNorm emitted, else one cast (autocast's input cast)."""
+    if prec != "bf16" or x32.dtype == torch.bfloat16:
+        return x32
+    xb = _fwd_take(x32)
+    return xb if xb is not None else ops.cast_bf16(x32)
+
+
+def _grad_copy(dy, prec):
+    """Incoming gradient in the compute dtype (the bf16 copy LayerNorm backward emitted, else one cast)."""
+    bf = prec == "bf16"
+    if bf and dy.dtype != torch.bfloat16:
+        dyc = _side_take(dy)
+        return dyc if dyc is not None else ops.cast_bf16(dy)
+    if not bf and dy.dtype != torch.float32:
+        return dy.float()
+    return dy
+
+
 class MlpFn(Function):
-    """y = residual + linear2(GELU(linear1(x))) as ONE autograd node (no inner dropout).  The forward GEMM of linear1 writes the pre-activation
-    and its GELU in one epilogue; the backward dX GEMM of linear2 multiplies by the GELU derivative in its epilogue - the stand-alone GELU
-    passes (read + write of the (M, mlp_dim) tensor, twice) disappear."""
+    """y = x + linear2(GELU(linear1(x))) on the fp32 stream x as ONE autograd node (no inner dropout).  The forward GEMM of linear1 writes the
+    pre-activation and its GELU in one epilogue; the backward dX GEMM of linear2 multiplies by the GELU derivative in its epilogue; and the
+    dX GEMM of linear1 adds the residual gradient in ITS epilogue - x has a single consumer, so autograd never runs its own accumulation add
+    (nor the bf16 -> fp32 copy in front of it)."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, residual, prec, wc):
+    def forward(ctx, x32, W1, b1, W2, b2, prec, wc):
         bf = prec == "bf16"
         cdt = torch.bfloat16 if bf else torch.float32
+        x = _compute_copy(x32, prec)
         a = torch.empty(x.shape[0], W1.shape[0], dtype=cdt, device=x.device)
         h = ops.gemm_nt(x, wc.w(W1, prec), wc.b(b1, prec), out_dtype=cdt, gelu=True, round_bf16=bf, pre_act=a)
-        y = ops.gemm_nt(h, wc.w(W2, prec), wc.b(b2, prec), residual=residual, out_dtype=torch.float32, round_bf16=bf)
+        y = ops.gemm_nt(h, wc.w(W2, prec), wc.b(b2, prec), residual=x32, out_dtype=torch.float32, round_bf16=bf)
         ctx.save_for_backward(x, a, h, W1, W2)
         ctx.prec, ctx.wc = prec, wc
         return y
@@ -135,29 +156,67 @@ class MlpFn(Function):
         x, a, h, W1, W2 = ctx.saved_tensors
         prec, wc, bf = ctx.prec, ctx.wc, ctx.prec == "bf16"
         dy = dy.contiguous()
-        dyc = dy
-        if bf and dy.dtype != torch.bfloat16:
-            dyc = _side_take(dy)
-            if dyc is None:
-                dyc = ops.cast_bf16(dy)
-        elif not bf and dy.dtype != torch.float32:
-            dyc = dy.float()
+        dyc = _grad_copy(dy, prec)
         da = ops.gemm_nt(dyc, wc.wt(W2, prec), out_dtype=a.dtype, round_bf16=bf, gelu_grad_of=a)     # (dY . W2) o gelu'(a)
         dW2 = ops.gemm(dyc, h, trans_a=True, trans_w=True, out_dtype=torch.float32) if ctx.needs_input_grad[3] else None
         db2 = ops.colsum(dyc) if ctx.needs_input_grad[4] else None
-        dx = ops.gemm_nt(da, wc.wt(W1, prec), out_dtype=x.dtype) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:   # branch gradient (rounded to the compute dtype as the unfused path does) + residual gradient, fp32
+            dx = ops.gemm_nt(da, wc.wt(W1, prec), residual=dy.float() if dy.dtype != torch.float32 else dy, out_dtype=torch.float32, round_bf16=bf)
         dW1 = ops.gemm(da, x, trans_a=True, trans_w=True, out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
         db1 = ops.colsum(da) if ctx.needs_input_grad[2] else None
-        return dx, dW1, db1, dW2, db2, dy, None, None
+        return dx, dW1, db1, dW2, db2, None, None
+
+
+class SelfAttnBlockFn(Function):
+    """y = x + out_proj(SDPA(in_proj(x))) on the fp32 stream x as one autograd node (no dropout): as MlpFn, the residual gradient is added in
+    the epilogue of the in-projection's dX GEMM."""
+
+    @staticmethod
+    def forward(ctx, x32, Wi, bi, Wo, bo, cu, H, max_len, causal, prec, wc):
+        bf = prec == "bf16"
+        cdt = torch.bfloat16 if bf else torch.float32
+        E = x32.shape[1]
+        dh = E // H
+        x = _compute_copy(x32, prec)
+        qkv = ops.gemm_nt(x, wc.w(Wi, prec), wc.b(bi, prec), out_dtype=cdt, round_bf16=bf)
+        lse = torch.empty(H * x.shape[0], dtype=torch.float32, device=x.device)
+        attn = ops.attn_varlen(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], cu, cu, H, dh, max_len, causal=causal, lse=lse)
+        y = ops.gemm_nt(attn, wc.w(Wo, prec), wc.b(bo, prec), residual=x32, out_dtype=torch.float32, round_bf16=bf)
+        ctx.save_for_backward(x, qkv, attn, lse, cu, Wi, Wo)
+        ctx.cfg = (H, dh, max_len, causal, prec, wc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, qkv, attn, lse, cu, Wi, Wo = ctx.saved_tensors
+        H, dh, max_len, causal, prec, wc = ctx.cfg
+        bf = prec == "bf16"
+        E = H * dh
+        dy = dy.contiguous()
+        dyc = _grad_copy(dy, prec)
+        dattn = ops.gemm_nt(dyc, wc.wt(Wo, prec), out_dtype=attn.dtype, round_bf16=bf)
+        dWo = ops.gemm(dyc, attn, trans_a=True, trans_w=True, out_dtype=torch.float32) if ctx.needs_input_grad[3] else None
+        dbo = ops.colsum(dyc) if ctx.needs_input_grad[4] else None
+        dqkv = torch.empty_like(qkv)
+        ops.attn_varlen_bwd(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], attn, dattn, lse, cu, cu, H, dh, max_len, max_len, causal,
+                            dqkv[:, :E], dqkv[:, E:2 * E], dqkv[:, 2 * E:])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm_nt(dqkv, wc.wt(Wi, prec), residual=dy.float() if dy.dtype != torch.float32 else dy, out_dtype=torch.float32, round_bf16=bf)
+        dWi = ops.gemm(dqkv, x, trans_a=True, trans_w=True, out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        dbi = ops.colsum(dqkv) if ctx.needs_input_grad[2] else None
+        return dx, dWi, dbi, dWo, dbo, None, None, None, None, None, None
 
 
 _FUSED_MLP = os.environ.get("ACAI_FUSED_MLP", "1") != "0"   # A/B aid
 
 
-def _mlp(xc, x32, lin1, lin2, p_inner, p_out, prec, wc):
-    """linear1 -> GELU -> (dropout) -> linear2 -> (dropout) + residual x32; xc = x32 in the compute dtype."""
+def _mlp(x32, lin1, lin2, p_inner, p_out, prec, wc):
+    """linear1 -> GELU -> (dropout) -> linear2 -> (dropout) + residual x32."""
     if _FUSED_MLP and p_inner <= 0.0 and p_out <= 0.0 and lin1.bias is not None and lin2.bias is not None:
-        return MlpFn.apply(xc, lin1.weight, lin1.bias, lin2.weight, lin2.bias, x32, prec, wc)
+        return MlpFn.apply(x32, lin1.weight, lin1.bias, lin2.weight, lin2.bias, prec, wc)
+    xc = CastBf16Fn.apply(x32) if prec == "bf16" else x32
     a = LinearFn.apply(xc, lin1.weight, lin1.bias, None, prec, wc, False)
     h = GeluFn.apply(a)
     if p_inner > 0:
@@ -332,6 +391,16 @@ def unpad_rows(padded, mask):
 
 
 # ---- building blocks ---------------------------------------------------------------------------------------------------------
+def _self_attn_block(x32, sa, cu, H, max_len, causal, p_attn, p_out, prec, wc):
+    """in_proj -> SDPA -> out_proj -> (dropout) + residual x32 (torch's _sa_block + residual)."""
+    if _FUSED_MLP and p_attn <= 0.0 and p_out <= 0.0 and sa.in_proj_bias is not None and sa.out_proj.bias is not None:
+        return SelfAttnBlockFn.apply(x32, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, cu, H, max_len, causal, prec, wc)
+    E = x32.shape[1]
+    qkv = _lin(x32, sa.in_proj_weight, sa.in_proj_bias, prec, wc)
+    attn = SelfAttnFn.apply(qkv, cu, H, E // H, max_len, causal, p_attn)
+    return _proj_residual(attn, sa.out_proj.weight, sa.out_proj.bias, x32, p_out, prec, wc)
+
+
 def _lin(x32, lin_w, lin_b, prec, wc, residual=None, out_fp32=False):
     """nn.Linear on an fp32 activation: casts to the compute dtype (autocast's input cast) and applies LinearFn."""
     x = CastBf16Fn.apply(x32) if (prec == "bf16" and x32.dtype != torch.bfloat16) else x32
@@ -345,12 +414,9 @@ def encoder_stack(stack, x32, cu, max_len, H, prec, wc, training=False):
     dh = E // H
     for layer in stack.layers:
         sa = layer.self_attn
-        qkv = _lin(x32, sa.in_proj_weight, sa.in_proj_bias, prec, wc)
-        attn = SelfAttnFn.apply(qkv, cu, H, dh, max_len, False, _p_of(sa, training))
-        y = _proj_residual(attn, sa.out_proj.weight, sa.out_proj.bias, x32, _p_of(layer.dropout1, training), prec, wc)
+        y = _self_attn_block(x32, sa, cu, H, max_len, False, _p_of(sa, training), _p_of(layer.dropout1, training), prec, wc)
         x32 = LayerNormFn.apply(y, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
-        xc = CastBf16Fn.apply(x32) if prec == "bf16" else x32
-        y = _mlp(xc, x32, layer.linear1, layer.linear2, _p_of(layer.dropout, training), _p_of(layer.dropout2, training), prec, wc)
+        y = _mlp(x32, layer.linear1, layer.linear2, _p_of(layer.dropout, training), _p_of(layer.dropout2, training), prec, wc)
         x32 = LayerNormFn.apply(y, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
     if stack.norm is not None:
         x32 = LayerNormFn.apply(x32, stack.norm.weight, stack.norm.bias, stack.norm.eps)
@@ -589,9 +655,7 @@ def decoder_forward(dec, input_seqs, img_latent, lmx_attention_mask, latent_atte
     for ly in dec.decoder_blocks.layers:
         sa, ca = ly.self_attn, ly.multihead_attn
         tr = dec.training
-        qkv = _lin(x32, sa.in_proj_weight, sa.in_proj_bias, prec, wc)
-        a = SelfAttnFn.apply(qkv, cu_t, H, dh, mt, True, _p_of(sa, tr))
-        y = _proj_residual(a, sa.out_proj.weight, sa.out_proj.bias, x32, _p_of(ly.dropout1, tr), prec, wc)
+        y = _self_attn_block(x32, sa, cu_t, H, mt, True, _p_of(sa, tr), _p_of(ly.dropout1, tr), prec, wc)
         x32 = LayerNormFn.apply(y, ly.norm1.weight, ly.norm1.bias, ly.norm1.eps)
         xc = CastBf16Fn.apply(x32) if bf else x32
         q = LinearFn.apply(xc, ca.in_proj_weight[:E], ca.in_proj_bias[:E], None, prec, _SliceCache(wc, ca, 0, E), False)
@@ -599,8 +663,7 @@ def decoder_forward(dec, input_seqs, img_latent, lmx_attention_mask, latent_atte
         a = CrossAttnFn.apply(q, kv, cu_t, cu_s, H, dh, mt, ms, _p_of(ca, tr))
         y = _proj_residual(a, ca.out_proj.weight, ca.out_proj.bias, x32, _p_of(ly.dropout2, tr), prec, wc)
         x32 = LayerNormFn.apply(y, ly.norm2.weight, ly.norm2.bias, ly.norm2.eps)
-        xc = CastBf16Fn.apply(x32) if prec == "bf16" else x32
-        y = _mlp(xc, x32, ly.linear1, ly.linear2, _p_of(ly.dropout, tr), _p_of(ly.dropout3, tr), prec, wc)
+        y = _mlp(x32, ly.linear1, ly.linear2, _p_of(ly.dropout, tr), _p_of(ly.dropout3, tr), prec, wc)
         x32 = LayerNormFn.apply(y, ly.norm3.weight, ly.norm3.bias, ly.norm3.eps)
     nrm = dec.decoder_blocks.norm
     x32 = LayerNormFn.apply(x32, nrm.weight, nrm.bias, nrm.eps)
