@@ -462,3 +462,44 @@ def test_full_size_encoder_and_head_vs_oracle(dev):
         assert md(lat[b, :n], lat_o[o:o + n]) < 1e-3, b
         assert md(mem[b, :n], mem_o[o:o + n]) < 1e-3, b
         o += n
+
+
+def test_full_length_decode_to_the_cache_limit_vs_oracle(dev):
+    """Full-size decoder, fp32, greedy to the LAST position of the 1536-token self-attention cache (1535 graph-replayed steps, cache
+    appends up to T_max - 1, positional rows up to 1535): token ids against the CPU oracle; a difference is only tolerated where the
+    oracle's own top-2 margin is below fp32 accumulation noise, and one more step must be refused as the reference refuses it."""
+    from acai_omr_amd.models.models import OMRDecoder, ViTOMR
+    from oracle import vitomr_oracle as O
+    torch.manual_seed(11)
+    T = 1536
+    dec = OMRDecoder(T, VOCAB, num_layers=12)
+    with torch.no_grad():
+        for n, p in dec.named_parameters():
+            if "norm" in n:
+                p.add_(0.1 * torch.randn_like(p))
+        dec.unembed.weight.mul_(6.0)
+        dec.unembed.bias[2] = -1.0e4      # never <eos>: the loop must run to the cache limit
+    cached = dec.to_cached_version(2, torch.float)
+    cached.load_state_dict(dec.state_dict())
+    model = ViTOMR(None, None, cached.to(dev).eval())
+    lens = [96, 40]
+    mem = torch.randn(sum(lens), 1024, generator=torch.Generator().manual_seed(12))
+    sd = {"decoder." + k: v for k, v in dec.state_dict().items()}
+    torch.set_num_threads(16)
+    oseqs, olps, omask, ologits = O.greedy_generate(mem, lens, sd, 16, "fp32", T, return_logits=True)
+    with torch.no_grad():
+        seqs, lps, mask = model._greedy_packed(mem.to(dev), None, lens, T)
+    assert seqs.shape == (2, T) and bool(mask.all())
+    same = seqs.cpu() == oseqs
+    top2 = ologits.topk(2, dim=-1).values
+    margin = top2[..., 0] - top2[..., 1]
+    for b in range(2):
+        bad = (~same[b]).nonzero()
+        if len(bad):
+            first = int(bad[0])
+            assert float(margin[b, first - 1]) < 2e-3, (b, first, float(margin[b, first - 1]))
+    assert float(same.float().mean()) > 0.5
+    eq = same.all(dim=1)
+    assert md(lps[eq], olps[eq]) < 2e-3
+    with pytest.raises(RuntimeError):
+        model._greedy_packed(mem.to(dev), None, lens, T + 1)
