@@ -511,6 +511,16 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(2))) v
     gemm_vec_epilogue<32>(g, acc, stg, bm0, bn0, wm, wn, lane);
 }
 
+// One 16-byte-per-lane LDS-DMA instruction from inline asm (hidden from the compiler's wait-count pass, see gemm_nt_glds3_kernel): M0 carries
+// the wave-uniform LDS destination; it is saved and restored around the instruction, so the asm has no reserved-register clobber.
+__device__ __forceinline__ void glds16(uint32_t lds_dst, const void *src) {
+    uint32_t m0_save;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_save)
+                 : "s"(lds_dst), "v"(src)
+                 : "memory");
+}
+
 // ---- 256x128 tile, 8 waves, THREE LDS stages (144 KB): two K-tiles in flight ------------------------------------------------------------
 // The two-stage kernels are latency-bound, not MFMA-bound (PMC: MFMA busy 36 %, a third of the wave cycles in s_waitcnt, L2 hit rate 64 %):
 // with one tile in flight per workgroup a CU has 64 KB outstanding, and 64 KB x 256 CUs / ~1.2 us of loaded L2/fabric latency is exactly the
@@ -577,12 +587,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
         for (int i = 0; i < GA; ++i) {
             const uint32_t dst = __builtin_amdgcn_readfirstlane(lbase + (wave * GA + i) * 1024);
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(srcA[i] + (size_t)kt * BK) : "memory", "m0");
+            glds16(dst, srcA[i] + (size_t)kt * BK);
         }
 #pragma unroll
         for (int i = 0; i < GW; ++i) {
             const uint32_t dst = __builtin_amdgcn_readfirstlane(lbase + BMT * ROWB + (wave * GW + i) * 1024);
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(srcW[i] + (size_t)kt * BK) : "memory", "m0");
+            glds16(dst, srcW[i] + (size_t)kt * BK);
         }
     };
     // Fragment read of logical 16-byte chunk c of tile row r goes to slot c ^ ((r >> 1) & 7).  A 256-byte bank row holds two tile rows, and a
@@ -801,12 +811,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
         for (int i = 0; i < GA; ++i) {
             const uint32_t dst = __builtin_amdgcn_readfirstlane(lb + (wave * GA + i) * 1024);
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(srcA[i] + (size_t)p_kt * BK) : "memory", "m0");
+            glds16(dst, srcA[i] + (size_t)p_kt * BK);
         }
 #pragma unroll
         for (int i = 0; i < GW; ++i) {
             const uint32_t dst = __builtin_amdgcn_readfirstlane(lb + BMT * ROWB + (wave * GW + i) * 1024);
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(srcW[i] + (size_t)p_kt * BK) : "memory", "m0");
+            glds16(dst, srcW[i] + (size_t)p_kt * BK);
         }
         if (++p_kt == nkt) {
             p_kt = 0;
@@ -1047,7 +1057,11 @@ int launch(const GemmArgs &g, hipStream_t st) {
     if (fast && !TA && !TB && g.K % BKG == 0 && !no_glds) {
         // Row-major LDS-DMA kernels.  variant (acai_gemm_set_variant / ACAI_GEMM_VARIANT; tests and A/B runs): 0 auto, 1 128x128 two-stage,
         // 2 256x128 two-stage, 3 256x128 three-stage, 4 256x128 persistent three-stage ring, 5 256x256 two-stage.
-        static const int n_cu = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        static const int n_cu = [] {
+            int dev = 0, n = 256;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+            return n > 0 ? n : 256;
+        }();
         const int nwg4 = cdiv(g.M, 256) * cdiv(g.N, BN), nwg256 = cdiv(g.M, 256) * cdiv(g.N, 256);
         int v = g_gemm_variant;
         // auto (tools/bench_gemm.py, bf16): up to 24 K-tiles the persistent ring wins (0.61-0.71 PF on K = 512..768 against 0.53-0.64 for
