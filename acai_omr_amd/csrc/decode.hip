@@ -612,13 +612,32 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DAttnArgs a) {
         if (s_last && tid < a.dhp) {
             float *p = a.partial + ((size_t)b * a.H + h) * a.nsplit * (a.dhp + 2);
             auto ld = [&](int i) { return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-            float M = -1.0e30f;
-            for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, ld(s * (a.dhp + 2)));
-            float l = 0.f, o = 0.f;
-            for (int s = 0; s < a.nsplit; ++s) {
-                const float w = fast_exp2(ld(s * (a.dhp + 2)) - M);
-                l += ld(s * (a.dhp + 2) + 1) * w;
-                o += ld(s * (a.dhp + 2) + 2 + tid) * w;
+            float M = -1.0e30f, l = 0.f, o = 0.f;
+            // the merge sits on the step's critical path: request all (max, sum, value) triples of up to 8 splits before touching any of them
+            // (a rolled loop issues one dependent L2 round trip after another: 3 x nsplit of them)
+            for (int s0 = 0; s0 < a.nsplit; s0 += 8) {
+                float pm[8], pl[8], po[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool in = s0 + u < a.nsplit;
+                    const int base = (in ? s0 + u : s0) * (a.dhp + 2);
+                    pm[u] = in ? ld(base) : -1.0e30f;
+                    pl[u] = in ? ld(base + 1) : 0.f;
+                    po[u] = in ? ld(base + 2 + tid) : 0.f;
+                }
+                float Mc = M;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) Mc = fmaxf(Mc, pm[u]);
+                const float resc = fast_exp2(M - Mc);
+                l *= resc;
+                o *= resc;
+                M = Mc;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float w = fast_exp2(pm[u] - M);
+                    l += pl[u] * w;
+                    o += po[u] * w;
+                }
             }
             if (tid < a.dh) {
                 float v = o / l;
@@ -799,22 +818,41 @@ __global__ __launch_bounds__(256) void decode_attn_gmfma_kernel(DAttnArgs a, int
             s_last = last;
         }
         __syncthreads();
-        if (s_last && tid < DHP) {
-            for (int g = 0; g < ng; ++g) {
+        if (s_last) {
+            // wave w merges rows w, w + 4, ...; all partial triples of up to 8 splits are requested before any is used
+            const int d = tid & 63;
+            for (int g = tid >> 6; g < ng; g += 4) {
                 float *pp = a.partial + ((size_t)(row0 + g) * a.H + h) * a.nsplit * (DHP + 2);
                 auto ld = [&](int i) { return __hip_atomic_load(pp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-                float M = -1.0e30f;
-                for (int s2 = 0; s2 < a.nsplit; ++s2) M = fmaxf(M, ld(s2 * (DHP + 2)));
-                float ls = 0.f, o = 0.f;
-                for (int s2 = 0; s2 < a.nsplit; ++s2) {
-                    const float w = fast_exp2(ld(s2 * (DHP + 2)) - M);
-                    ls += ld(s2 * (DHP + 2) + 1) * w;
-                    o += ld(s2 * (DHP + 2) + 2 + tid) * w;
+                float M = -1.0e30f, ls = 0.f, o = 0.f;
+                for (int s0 = 0; s0 < a.nsplit; s0 += 8) {
+                    float pm[8], pl[8], po[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const bool in = s0 + u < a.nsplit;
+                        const int base = (in ? s0 + u : s0) * (DHP + 2);
+                        pm[u] = in ? ld(base) : -1.0e30f;
+                        pl[u] = in ? ld(base + 1) : 0.f;
+                        po[u] = in ? ld(base + 2 + d) : 0.f;
+                    }
+                    float Mc = M;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) Mc = fmaxf(Mc, pm[u]);
+                    const float resc = fast_exp2(M - Mc);
+                    ls *= resc;
+                    o *= resc;
+                    M = Mc;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float w = fast_exp2(pm[u] - M);
+                        ls += pl[u] * w;
+                        o += po[u] * w;
+                    }
                 }
-                if (tid < a.dh) {
+                if (d < a.dh) {
                     float v = o / ls;
                     if (a.round_out) v = round_bf16(v);
-                    a.out[(size_t)(row0 + g) * a.ldo + h * a.dh + tid] = v;
+                    a.out[(size_t)(row0 + g) * a.ldo + h * a.dh + d] = v;
                 }
             }
         }
