@@ -890,14 +890,15 @@ __global__ __launch_bounds__(256) void embed_kernel(const float *emb, const floa
 __global__ void set_step_kernel(int32_t *step, int t) { step[0] = t; }
 
 // cached_get_next_token (M:579-581) + loop bookkeeping (M:606-611).  One workgroup, wave w takes rows w, w+4, ...
-__global__ __launch_bounds__(256) void argmax_logprob_kernel(const float *logits, int V, int B, int64_t *seqs, float *logprobs,
+__global__ __launch_bounds__(1024) void argmax_logprob_kernel(const float *logits, int V, int B, int64_t *seqs, float *logprobs,
                                                              int max_len, int32_t *step, int32_t *finished, int eos, int round_lp,
                                                              int bookkeeping) {
-    __shared__ int unfinished[4];
+    __shared__ int unfinished[16];   // up to 16 waves: one row per wave for the usual batch sizes (the rows of a wave run back to back)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = step[0];
     int cnt = 0;
-    for (int b = wave; b < B; b += 4) {
+    const int nw = blockDim.x >> 6;
+    for (int b = wave; b < B; b += nw) {
         const float *lg = logits + (size_t)b * V;
         float best = -INFINITY;
         int bi = 0x7fffffff;
@@ -939,7 +940,9 @@ __global__ __launch_bounds__(256) void argmax_logprob_kernel(const float *logits
     if (lane == 0) unfinished[wave] = cnt;
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (bookkeeping) finished[B] = unfinished[0] + unfinished[1] + unfinished[2] + unfinished[3];
+        int tot = 0;
+        for (int w = 0; w < nw; ++w) tot += unfinished[w];
+        if (bookkeeping) finished[B] = tot;
         step[0] = t + 1;
         step[1] = step[1] + 1;
     }
@@ -1291,7 +1294,7 @@ extern "C" int acai_decode_step(const AcaiDecoder *d, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     rc = d->dtype == ACAI_BF16 ? decode_core<bf16_t>(d, nullptr, st) : decode_core<float>(d, nullptr, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(argmax_logprob_kernel, dim3(1), dim3(256), 0, st, d->logits, d->V, d->B, d->seqs, d->logprobs, d->max_len, d->step,
+    hipLaunchKernelGGL(argmax_logprob_kernel, dim3(1), dim3(d->B > 8 ? 1024 : (d->B > 4 ? 512 : 256)), 0, st, d->logits, d->V, d->B, d->seqs, d->logprobs, d->max_len, d->step,
                        d->finished, d->eos, (d->flags & ACAI_GEMM_ROUND_BF16) ? 1 : 0, 1);
     ACAI_LAUNCH_CHECK("argmax_logprob");
     return 0;
