@@ -1068,7 +1068,8 @@ int launch(const GemmArgs &g, hipStream_t st) {
         // one tile per workgroup); from 64 K-tiles the 256x256 tile does (1.00-1.02 PF at 4096^3 / 8192^3 against 0.95-0.98); between, the
         // three-stage 256x128 kernel; small problems keep two 128x128 workgroups per CU.
         const int ktiles = g.K / BKG;
-        if (v == 0) v = nwg4 >= 512 ? (ktiles <= 24 ? 4 : (ktiles >= 64 && nwg256 >= n_cu ? 5 : 3)) : 1;
+        // (fp32: the 256x256 tile never beats the three-stage kernel - 102 against 137 TF at 32768 x 768 x 3072 - and a K-tile is 32 floats)
+        if (v == 0) v = nwg4 >= 512 ? (ktiles <= 24 ? 4 : (sizeof(T) == 2 && ktiles >= 64 && nwg256 >= n_cu ? 5 : 3)) : 1;
         if (v == 5 && nwg256 < 8) v = 1;
         if (v == 4 && nwg4 < 8) v = 1;
         switch (v) {
