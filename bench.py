@@ -34,16 +34,18 @@ def build_model(device, batch, cache_dtype=torch.bfloat16):
 
 
 def time_cross_attn_kernel(eng, iters=48):
-    """Average duration of ONE launch of the dominant kernel (decode_attn_kernel<bf16, 8, RAGGED>), cycling over the 12
-    layers' K/V so that every launch streams from HBM as it does inside a step (12 x 134 MB >> 256 MB Infinity Cache)."""
+    """Average duration of ONE launch of the dominant kernel (decode_attn_kernel<bf16, 8, RAGGED>) exactly as a decode step launches it
+    (split over the memory, partials merged inside the launch by the last-arriving workgroup), cycling over the 12 layers' K/V so that every
+    launch streams from HBM as it does inside a step (12 x 134 MB >> 256 MB Infinity Cache).  HIP events on the launch stream."""
     import ctypes
 
     from acai_omr_amd import _lib, ops
     L = _lib.lib()
     q = torch.randn(eng.B, 3 * eng.E, device=eng.device)
+    out = eng.ws["attn"]
     args = lambda l: (q.data_ptr(), q.stride(0), eng.k_cross[l].data_ptr(), eng.v_cross[l].data_ptr(), eng.cross_off.data_ptr(),  # noqa: E731
-                      eng.cross_len.data_ptr(), eng.partial.data_ptr(), None, 0, eng.B, eng.H, eng.dh, eng.dhp, eng.CROSS_CHUNK,
-                      eng.cross_nsplit, _lib.ACAI_BF16 if eng.bf else _lib.ACAI_F32, 0, None, ops._st())
+                      eng.cross_len.data_ptr(), eng.partial.data_ptr(), out.data_ptr(), out.stride(0), eng.B, eng.H, eng.dh, eng.dhp, eng.CROSS_CHUNK,
+                      eng.cross_nsplit, _lib.ACAI_BF16 if eng.bf else _lib.ACAI_F32, 1 if eng.bf else 0, eng.tickets.data_ptr(), ops._st())
     for l in range(eng.L):
         _lib.check(L.acai_decode_attn(*args(l)), "acai_decode_attn")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
