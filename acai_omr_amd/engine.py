@@ -182,6 +182,9 @@ class DecodeEngine:
         self.stream = torch.cuda.Stream(device=device)  # capture / replay stream (the legacy default stream cannot capture)
         self.B = 0
         self.lens = None
+        self.group = 1          # decode rows per stored cross K/V (GRPO rollout groups)
+        self._sampler = None    # (top_k, temperature) while a sampling rollout runs, else greedy
+        self.uniforms = None    # (Bmax, Tmax) uniforms of the sampling step, allocated on first use
         self.cache_len = 0
         self._desc = None
         self._keep = None
@@ -261,7 +264,7 @@ class DecodeEngine:
         d.dtype = _lib.ACAI_BF16 if self.bf else _lib.ACAI_F32
         d.flags = _lib.GEMM_ROUND_BF16 if self.bf else 0
         d.max_len = self.Tmax
-        d.cross_group = getattr(self, "group", 1)
+        d.cross_group = self.group
         d.self_chunk, d.cross_chunk, d.self_nsplit, d.cross_nsplit = self.SELF_CHUNK, self.CROSS_CHUNK, self.self_nsplit, self.cross_nsplit
         d.layers = ctypes.cast(layers, ctypes.POINTER(_lib.AcaiDecLayer))
         top = {}
@@ -329,7 +332,7 @@ class DecodeEngine:
         if max_actions > self.Tmax:
             raise RuntimeError(f"{max_actions} decoding steps is too long for max sequence length of {self.Tmax}")
         B = self.B
-        if getattr(self, "uniforms", None) is None:
+        if self.uniforms is None:
             self.uniforms = torch.zeros(self.Bmax, self.Tmax, dtype=torch.float32, device=self.device)
         if uniforms is None:
             uniforms = torch.rand(B, max_actions, device=self.device)
@@ -383,7 +386,7 @@ class DecodeEngine:
 
     def _step(self, st):
         """One decode step on the current stream: greedy, or (self._sampler = (top_k, temperature)) a sampling step."""
-        smp = getattr(self, "_sampler", None)
+        smp = self._sampler
         if smp is None:
             _lib.check(_lib.lib().acai_decode_step(ctypes.byref(self._desc), st), "acai_decode_step")
         else:
@@ -393,7 +396,7 @@ class DecodeEngine:
     def ensure_graph(self, nsteps=1):
         """hipGraph of `nsteps` consecutive decode steps for the current (B, cross split) configuration.  Must run on self.stream."""
         B = self.B
-        key = (B, self.cross_nsplit, nsteps, getattr(self, "_sampler", None), getattr(self, "group", 1))
+        key = (B, self.cross_nsplit, nsteps, self._sampler, self.group)
         g = self.graphs.get(key)
         if g is None:
             st = ops._st()
