@@ -503,3 +503,23 @@ def test_full_length_decode_to_the_cache_limit_vs_oracle(dev):
     assert md(lps[eq], olps[eq]) < 2e-3
     with pytest.raises(RuntimeError):
         model._greedy_packed(mem.to(dev), None, lens, T + 1)
+
+
+def test_decode_is_deterministic_run_to_run(dev):
+    """Two graph-replayed greedy decodes of the same ragged batch give bit-identical ids and log-probs: the in-launch split merge (whichever
+    workgroup arrives last merges) and the device-side loop state leave no run-to-run freedom (tools/soak_decode.py is the long form)."""
+    from acai_omr_amd.models.models import OMRDecoder, ViTOMR
+    torch.manual_seed(21)
+    dec = OMRDecoder(128, VOCAB, num_layers=4)
+    cached = dec.to_cached_version(4, torch.bfloat16)
+    cached.load_state_dict(dec.state_dict())
+    model = ViTOMR(None, None, cached.to(dev).eval())
+    lens = [2100, 1300, 3000]
+    mem = torch.randn(sum(lens), 1024, generator=torch.Generator().manual_seed(22)).to(dev).to(torch.bfloat16)
+    outs = []
+    with torch.no_grad():
+        for _ in range(3):
+            seqs, lps, mask = model._greedy_packed(None, mem, lens, 96)
+            outs.append((seqs.clone(), lps.clone()))
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
