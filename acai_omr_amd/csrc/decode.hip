@@ -468,12 +468,14 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DAttnArgs a) {
     float *part = a.partial + (((size_t)b * a.H + h) * a.nsplit + split) * (a.dhp + 2);
     const int c0 = split * a.chunk, c1 = min(len, c0 + a.chunk);
     const bool fused_merge = a.tickets && a.out && a.nsplit > 1;
-    if (c0 >= len) {  // empty split: neutral element
+    if (c0 >= len) {  // empty split: neutral element (m = -1e30, l = 0, o = 0)
         if (tid < a.dhp + 2) {
             if (fused_merge) __hip_atomic_store(part + tid, tid == 0 ? -1.0e30f : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else part[tid] = tid == 0 ? -1.0e30f : 0.f;
         }
         if (!fused_merge) return;
+        // the neutral stores of wave 1 (elements 64, 65) must be drained before wave 0 takes the ticket below
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     const TC *Kp = reinterpret_cast<const TC *>(a.kc) + base;
     const TC *Vp = reinterpret_cast<const TC *>(a.vc) + base;
@@ -571,80 +573,89 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DAttnArgs a) {
         for (int e = 0; e < EPC; ++e) red[wave][2 + kq * EPC + e] = acc[e];
     }
     __syncthreads();
-    if (tid < a.dhp + 2) {
-        const float M = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
-        float v = 0.f, lsum = 0.f;
+    if (wave != 0) return;
+    // Wave 0 finishes alone - lane d owns output dim d - so the tail needs no workgroup barrier: combine the four waves, publish the split's
+    // partial (write-through), drain, take the ticket, and (last arrival only) merge all splits.
+    const int d = lane;
+    const float M = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
+    float v = 0.f, lsum = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float f = fast_exp2(red[w][0] - M);
-            v += red[w][tid] * f;
-            lsum += red[w][1] * f;
+    for (int w = 0; w < 4; ++w) {
+        const float f = fast_exp2(red[w][0] - M);
+        v += red[w][2 + d] * f;
+        lsum += red[w][1] * f;
+    }
+    if (a.nsplit == 1 && a.out) {
+        if (d < a.dh) {
+            float o = v / lsum;
+            if (a.round_out) o = round_bf16(o);
+            a.out[(size_t)b * a.ldo + h * a.dh + d] = o;
         }
-        if (a.nsplit == 1 && a.out) {
-            const int d = tid - 2;
-            if (d >= 0 && d < a.dh) {
-                float o = v / lsum;
-                if (a.round_out) o = round_bf16(o);
-                a.out[(size_t)b * a.ldo + h * a.dh + d] = o;
+        return;
+    }
+    if (c0 < len && d < a.dhp) {
+        // fused merge: write-through (sc1) stores, so the hand-off needs no release fence (an L2 write-back per workgroup)
+        if (fused_merge) {
+            __hip_atomic_store(part + 2 + d, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == 0) {
+                __hip_atomic_store(part, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(part + 1, lsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-        } else if (c0 < len) {
-            // fused merge: write-through (sc1) stores, so the hand-off needs no release fence (an L2 write-back per workgroup)
-            if (fused_merge) __hip_atomic_store(part + tid, tid == 0 ? M : v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else part[tid] = tid == 0 ? M : v;
+        } else {
+            part[2 + d] = v;
+            if (d == 0) {
+                part[0] = M;
+                part[1] = lsum;
+            }
         }
     }
-    if (fused_merge) {
-        // In-launch merge of the split partials (placement-independent hand-off, write-through form): the partials were
-        // stored sc1 (agent-scope atomic stores), every storing wave drains its stores, the workgroup meets, ONE lane takes
-        // a ticket with an agent-scope atomic add; the workgroup that draws nsplit-1 reads every partial with sc1 loads
-        // (agent-scope atomic loads bypass this CU's L1) after a workgroup barrier and merges.  The counter re-arms itself.
-        __shared__ int s_last;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            unsigned *cnt = a.tickets + (size_t)b * a.H + h;
-            const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = t == (unsigned)(a.nsplit - 1);
-            if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = last;
+    if (!fused_merge) return;
+    // In-launch merge of the split partials (placement-independent hand-off, write-through form): the partials were stored sc1 (agent-scope
+    // atomic stores) by this wave, which drains them, then its lane 0 takes a ticket with an agent-scope atomic add; the wave that draws
+    // nsplit-1 reads every partial with sc1 loads (agent-scope atomic loads bypass this CU's L1) and merges.  The counter re-arms itself.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int last = 0;
+    if (lane == 0) {
+        unsigned *cnt = a.tickets + (size_t)b * a.H + h;
+        const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == (unsigned)(a.nsplit - 1);
+        if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!last || d >= a.dhp) return;
+    float *p = a.partial + ((size_t)b * a.H + h) * a.nsplit * (a.dhp + 2);
+    auto ld = [&](int i) { return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    float Mm = -1.0e30f, lm = 0.f, om = 0.f;
+    // the merge sits on the step's critical path: request all (max, sum, value) triples of up to 8 splits before touching any of them
+    // (a rolled loop issues one dependent L2 round trip after another: 3 x nsplit of them)
+    for (int s0 = 0; s0 < a.nsplit; s0 += 8) {
+        float pm[8], pl[8], po[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool in = s0 + u < a.nsplit;
+            const int pb = (in ? s0 + u : s0) * (a.dhp + 2);
+            pm[u] = in ? ld(pb) : -1.0e30f;
+            pl[u] = in ? ld(pb + 1) : 0.f;
+            po[u] = in ? ld(pb + 2 + d) : 0.f;
         }
-        __syncthreads();
-        if (s_last && tid < a.dhp) {
-            float *p = a.partial + ((size_t)b * a.H + h) * a.nsplit * (a.dhp + 2);
-            auto ld = [&](int i) { return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-            float M = -1.0e30f, l = 0.f, o = 0.f;
-            // the merge sits on the step's critical path: request all (max, sum, value) triples of up to 8 splits before touching any of them
-            // (a rolled loop issues one dependent L2 round trip after another: 3 x nsplit of them)
-            for (int s0 = 0; s0 < a.nsplit; s0 += 8) {
-                float pm[8], pl[8], po[8];
+        float Mc = Mm;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const bool in = s0 + u < a.nsplit;
-                    const int base = (in ? s0 + u : s0) * (a.dhp + 2);
-                    pm[u] = in ? ld(base) : -1.0e30f;
-                    pl[u] = in ? ld(base + 1) : 0.f;
-                    po[u] = in ? ld(base + 2 + tid) : 0.f;
-                }
-                float Mc = M;
+        for (int u = 0; u < 8; ++u) Mc = fmaxf(Mc, pm[u]);
+        const float resc = fast_exp2(Mm - Mc);
+        lm *= resc;
+        om *= resc;
+        Mm = Mc;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) Mc = fmaxf(Mc, pm[u]);
-                const float resc = fast_exp2(M - Mc);
-                l *= resc;
-                o *= resc;
-                M = Mc;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float w = fast_exp2(pm[u] - M);
-                    l += pl[u] * w;
-                    o += po[u] * w;
-                }
-            }
-            if (tid < a.dh) {
-                float v = o / l;
-                if (a.round_out) v = round_bf16(v);
-                a.out[(size_t)b * a.ldo + h * a.dh + tid] = v;
-            }
+        for (int u = 0; u < 8; ++u) {
+            const float w = fast_exp2(pm[u] - Mm);
+            lm += pl[u] * w;
+            om += po[u] * w;
         }
+    }
+    if (d < a.dh) {
+        float o = om / lm;
+        if (a.round_out) o = round_bf16(o);
+        a.out[(size_t)b * a.ldo + h * a.dh + d] = o;
     }
 }
 
