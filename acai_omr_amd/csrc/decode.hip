@@ -183,35 +183,52 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
     // row block re-read its weights from L2 instead of queueing four latency chains inside one workgroup (64 rows: 24 -> 17 us per launch)
     for (int bt = blockIdx.y * 16; bt < a.B; bt += 16 * gridDim.y) {
         const int nb = min(16, a.B - bt);
-        // 1. first batch of weight fragments in flight
+        // 1. first batch of weight fragments.  Loads return in issue order, so whatever is requested first is waited for first: the activation
+        // rows (whose consumer chain - statistics, LDS image, barrier - is the long one) are requested BEFORE the weights and the epilogue
+        // operands, which are only needed after the barrier (+1-2 % tokens/s over weights-first on the same box).
         uint4 wf[8];
+        bool w_requested = false;
+        auto request_weights = [&]() {
+            if (w_requested) return;
+            w_requested = true;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            wf[c] = make_uint4(0, 0, 0, 0);
-            if (c < nch && row_ok) wf[c] = (a.ablate & 8) ? *reinterpret_cast<const uint4 *>(Wrow + 32 * c) : ld_nt16(Wrow + 32 * c);
-        }
+            for (int c = 0; c < 8; ++c) {
+                wf[c] = make_uint4(0, 0, 0, 0);
+                if (c < nch && row_ok) wf[c] = (a.ablate & 8) ? *reinterpret_cast<const uint4 *>(Wrow + 32 * c) : ld_nt16(Wrow + 32 * c);
+            }
+        };
+        constexpr bool X_FIRST = !XBF16 && NV <= 4;   // (the bf16-input and NV = 16 paths keep weights first)
         // 1b. wave 0 also fetches everything its epilogue needs now, so that nothing is loaded after the reduction
         float e_bias[4] = {0.f, 0.f, 0.f, 0.f}, e_res[4] = {0.f, 0.f, 0.f, 0.f}, e_rw[4] = {1.f, 1.f, 1.f, 1.f}, e_rb[4] = {0.f, 0.f, 0.f, 0.f};
         float rmean = 0.f, rrstd = 1.f;
-        if (wave == 0) {
-            const int b = bt + r;
-            const bool col_ok = r < nb;
-            if (a.rln_w && col_ok) {
-                rmean = a.rstats[b * 2];
-                rrstd = a.rstats[b * 2 + 1];
-            }
+        bool e_requested = false;
+        auto request_epilogue = [&]() {
+            if (e_requested) return;
+            e_requested = true;
+            if (wave == 0) {
+                const int b = bt + r;
+                const bool col_ok = r < nb;
+                if (a.rln_w && col_ok) {
+                    rmean = a.rstats[b * 2];
+                    rrstd = a.rstats[b * 2 + 1];
+                }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = n0 + 4 * q + i;
-                if (4 * q + i < R && n < a.N) {
-                    if (a.bias) e_bias[i] = a.bias[n];
-                    if (a.residual && col_ok) e_res[i] = a.residual[(size_t)b * a.ldr + n];
-                    if (a.rln_w) {
-                        e_rw[i] = a.rln_w[n];
-                        e_rb[i] = a.rln_b[n];
+                for (int i = 0; i < 4; ++i) {
+                    const int n = n0 + 4 * q + i;
+                    if (4 * q + i < R && n < a.N) {
+                        if (a.bias) e_bias[i] = a.bias[n];
+                        if (a.residual && col_ok) e_res[i] = a.residual[(size_t)b * a.ldr + n];
+                        if (a.rln_w) {
+                            e_rw[i] = a.rln_w[n];
+                            e_rb[i] = a.rln_b[n];
+                        }
                     }
                 }
             }
+        };
+        if (!X_FIRST) {
+            request_weights();
+            request_epilogue();
         }
         // 2. activation image: wave w takes rows w, w+4 (together), then w+8, w+12; lane takes 4-element groups
         if (a.ablate & 2) {
@@ -240,6 +257,8 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
                             lb[j] = *reinterpret_cast<const float4 *>(a.ln_b + j * 256 + lane * 4);
                         }
                     }
+                request_weights();   // behind this wave's activation rows
+                request_epilogue();
                 if (a.ln_w) {
                     // both rows' sum and sum of squares ride the same 6 cross-lane steps (4 independent chains); one-pass variance
                     // E[x^2] - mean^2 is accurate to ~1e-6 relative for O(1) activations and this path rounds to bf16 right after
@@ -315,6 +334,8 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
                     }
             }
         }
+        request_weights();   // waves without an activation row of this tile
+        request_epilogue();
         __syncthreads();
         // 3. MFMA over this wave's K slice; batch columns >= nb read row 0 (their outputs are never stored)
         const unsigned char *xfrag = xs + (r < nb ? r : 0) * pitch + (kbase + 8 * q) * 2;
