@@ -9,7 +9,7 @@
 //                    S^T = K Q^T, P^T = 2^(c S^T - lse),  dP^T = V dO^T,  dS^T = P^T o (dP^T - delta),  dQ^T += K^T dS^T
 //   attn_bwd_dkv : workgroup = 128 keys (key on the lane), streams 64-query tiles:
 //                    S = Q K^T,  P,  dV^T += dO^T P,  dP = dO V^T,  dS = P o (dP - delta),  dK^T += Q^T dS
-// delta[q] = sum_d dO[q,d] O[q,d] comes from attn_delta_kernel.  S and P are recomputed in both kernels (7 products instead
+// delta[q] = sum_d dO[q,d] O[q,d] is formed in the prologue of attn_bwd_dq (which runs first) and published for attn_bwd_dkv.  S and P are recomputed in both kernels (7 products instead
 // of 5) - the price of having no cross-workgroup reduction.  fp32: v_mfma_f32_32x32x2_f32, bf16: v_mfma_f32_32x32x16_bf16.
 #include "common.h"
 #include <type_traits>
@@ -182,29 +182,6 @@ struct TileStager {
 };
 
 
-// delta[h][q] = sum_d dO[q, h*dh + d] * O[q, h*dh + d]; one thread per (q, h), 16-byte loads when the head slice allows it
-template <typename T, bool VEC>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const T *o, int ldo, const T *dout, int lddo, float *delta, int total_q, int H, int dh) {
-    constexpr int EPC = 16 / sizeof(T);
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total_q * H) return;
-    const int q = idx / H, h = idx - q * H;
-    const T *po = o + (size_t)q * ldo + h * dh, *pd = dout + (size_t)q * lddo + h * dh;
-    float s = 0.f;
-    if constexpr (VEC) {
-        for (int d = 0; d < dh; d += EPC) {
-            union { uint4 v; T e[EPC]; } a, b;
-            a.v = *reinterpret_cast<const uint4 *>(po + d);
-            b.v = *reinterpret_cast<const uint4 *>(pd + d);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) s += DT<T>::ld(&a.e[e]) * DT<T>::ld(&b.e[e]);
-        }
-    } else {
-        for (int d = 0; d < dh; ++d) s += DT<T>::ld(po + d) * DT<T>::ld(pd + d);
-    }
-    delta[(size_t)h * total_q + q] = s;
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename T, int DHP, bool FAST, bool DROP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dq_kernel(BwdArgs a) {
@@ -234,7 +211,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         dof[s] = ld16<T, FAST>(DO, a.lddo, my_q, lq, (s * 32 + lh * 16) / ES, dh);
     }
     const size_t sidx = (size_t)h * a.total_q + q_start + (my_q < lq ? my_q : 0);
-    const float lse = a.lse[sidx], dlt = a.delta[sidx];
+    const float lse = a.lse[sidx];
+    // delta[q] = sum_d dO[q,d] O[q,d]: this lane holds its half of the row of dO already; O is read the same way, the two halves meet with one
+    // cross-lane add, and the value is published for the dK/dV kernel that follows in the stream (no separate pass over O and dO)
+    float dlt = 0.f;
+    {
+        const T *O = reinterpret_cast<const T *>(a.o) + (size_t)q_start * a.ldo + h * dh;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const uint4 of = ld16<T, FAST>(O, a.ldo, my_q, lq, (s * 32 + lh * 16) / ES, dh);
+            if constexpr (ES == 2) {
+                const uint32_t ow[4] = {of.x, of.y, of.z, of.w}, dw[4] = {dof[s].x, dof[s].y, dof[s].z, dof[s].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dlt = fmaf(__uint_as_float(ow[e] << 16), __uint_as_float(dw[e] << 16), dlt);
+                    dlt = fmaf(__uint_as_float(ow[e] & 0xffff0000u), __uint_as_float(dw[e] & 0xffff0000u), dlt);
+                }
+            } else {
+                const f32x4 o4 = __builtin_bit_cast(f32x4, of), d4 = __builtin_bit_cast(f32x4, dof[s]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dlt = fmaf(o4[e], d4[e], dlt);
+            }
+        }
+        dlt += __shfl_xor(dlt, 32);
+        if (lh == 0 && my_q < lq) const_cast<float *>(a.delta)[sidx] = dlt;
+    }
 
     f32x16 dqacc[NDB];
 #pragma unroll
@@ -448,8 +449,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) 
 template <typename T, int DHP>
 int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, hipStream_t st) {
     constexpr int ES = sizeof(T), EPC = 16 / ES;
-    const bool fast = (a.dh % EPC == 0) && (a.ldq % EPC == 0) && (a.ldk % EPC == 0) && (a.ldv % EPC == 0) && (a.lddo % EPC == 0) &&
-                      aligned16(a.q) && aligned16(a.k) && aligned16(a.v) && aligned16(a.dout);
+    const bool fast = (a.dh % EPC == 0) && (a.ldq % EPC == 0) && (a.ldk % EPC == 0) && (a.ldv % EPC == 0) && (a.lddo % EPC == 0) && (a.ldo % EPC == 0) &&
+                      aligned16(a.q) && aligned16(a.k) && aligned16(a.v) && aligned16(a.dout) && aligned16(a.o);
     constexpr int RP = TileLayout<ES, DHP>::PITCH;
     const size_t lds_dq = 2 * (2 * TT * RP), lds_dkv = 2 * (2 * TT * RP + 2 * TT * sizeof(float));   // two stages each
     auto launch_pair = [&](auto drop, auto fst) {
@@ -464,14 +465,6 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, hipStream_t st) {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DHP, F, D>), gq, dim3(256), lds_dq, st, a);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DHP, F, D>), gk, dim3(256), lds_dkv, st, a);
     };
-    const bool vec = (a.dh % EPC == 0) && (a.ldo % EPC == 0) && (a.lddo % EPC == 0) && aligned16(a.o) && aligned16(a.dout);
-    if (vec)
-        hipLaunchKernelGGL((attn_delta_kernel<T, true>), dim3(cdiv(a.total_q * a.H, 256)), dim3(256), 0, st, (const T *)a.o, a.ldo, (const T *)a.dout,
-                           a.lddo, const_cast<float *>(a.delta), a.total_q, a.H, a.dh);
-    else
-        hipLaunchKernelGGL((attn_delta_kernel<T, false>), dim3(cdiv(a.total_q * a.H, 256)), dim3(256), 0, st, (const T *)a.o, a.ldo, (const T *)a.dout,
-                           a.lddo, const_cast<float *>(a.delta), a.total_q, a.H, a.dh);
-    ACAI_LAUNCH_CHECK("attn_delta");
     if (a.drop_thr) {
         if (fast) launch_pair(std::true_type{}, std::true_type{});
         else launch_pair(std::true_type{}, std::false_type{});
