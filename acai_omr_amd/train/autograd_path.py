@@ -445,6 +445,20 @@ def _patches(enc, imgs, prec, select=None):
     return patches, dims, lens
 
 
+_GRID_ROWS = {}
+
+
+def _grid_rows(h_p, w_p, Wm, dev):
+    """Row indices of the (h_p, w_p) top-left block of a PE table with Wm columns (int32, on the device, cached)."""
+    key = (h_p, w_p, Wm, str(dev))
+    t = _GRID_ROWS.get(key)
+    if t is None:
+        t = (torch.arange(h_p, dtype=torch.int32).unsqueeze(1) * Wm + torch.arange(w_p, dtype=torch.int32).unsqueeze(0)).reshape(-1).to(dev)
+        if len(_GRID_ROWS) < 256:
+            _GRID_ROWS[key] = t
+    return t
+
+
 def _pe_rows(enc, table_param, dims, select=None):
     """Differentiable pos_embedding[:h_p,:w_p] rows (optionally a subset per image) of every image, packed."""
     dev, E = table_param.device, table_param.shape[-1]
@@ -453,11 +467,11 @@ def _pe_rows(enc, table_param, dims, select=None):
     for i, (h_p, w_p) in enumerate(dims):
         if h_p > table_param.shape[0] or w_p > Wm:
             raise NotImplementedError("PE interpolation in the training path is not built (inference path only)")
-        rows = (torch.arange(h_p, dtype=torch.int32).unsqueeze(1) * Wm + torch.arange(w_p, dtype=torch.int32).unsqueeze(0)).reshape(-1)
+        rows = _grid_rows(h_p, w_p, Wm, dev)
         if select is not None:
-            rows = rows[select[i].cpu()]
+            rows = rows[select[i].to(dev)]   # device gather: no host round trip per image
         idx.append(rows)
-    return GatherRowsFn.apply(table_param.reshape(-1, E), torch.cat(idx).to(dev), None)
+    return GatherRowsFn.apply(table_param.reshape(-1, E), torch.cat(idx), None)
 
 
 def encoder_forward_packed(enc, x):
@@ -494,15 +508,25 @@ def _mae_prepare(mae, x, noises):
     enc = mae.encoder
     imgs = _as_image_list(x, enc._device())
     dims = [enc._grid(t) for t in imgs]
-    keep, restore, smask, kept = [], [], [], []
+    # mask_sequence (models.py:106-119) for every image; images with the same patch count share ONE batched argsort pair (the reference sorts
+    # image by image: 2 x batch sort launches per step).  Everything stays on the device: no host round trip per image.
+    dev = enc._device()
+    B = len(dims)
+    keep, restore, smask, kept = [None] * B, [None] * B, [None] * B, [None] * B
+    groups = {}
     for i, (h, w) in enumerate(dims):
-        n = h * w
-        noise = None if noises is None else noises[i].to(enc._device())
-        ids_keep, ids_restore, seq_mask, k = enc.mask_ids(n, enc._device(), noise)
-        keep.append(ids_keep)
-        restore.append(ids_restore)
-        smask.append(seq_mask)
-        kept.append(k)
+        groups.setdefault(h * w, []).append(i)
+    for n, members in groups.items():
+        k = int(n * (1 - enc.mask_ratio))
+        if noises is None:
+            noise = torch.rand(len(members), n, device=dev)
+        else:
+            noise = torch.stack([noises[i].to(dev).reshape(n) for i in members])
+        ids_shuffle = torch.argsort(noise, dim=1)
+        ids_restore = torch.argsort(ids_shuffle, dim=1)
+        seq_mask = (ids_restore >= k).to(torch.int)          # = ones with [:k] zeroed, gathered by ids_restore
+        for j, i in enumerate(members):
+            keep[i], restore[i], smask[i], kept[i] = ids_shuffle[j, :k], ids_restore[j], seq_mask[j], k
     return imgs, dims, keep, restore, smask, kept
 
 
@@ -559,11 +583,10 @@ def mae_forward(mae, batch, noises=None, packed=False):
     Mk = lat.shape[0]
     idx, o = [], 0
     for k, n, r in zip(kept, lens, restore):
-        r = r.cpu()
-        idx.append(torch.where(r < k, r + o, torch.full_like(r, Mk)).to(torch.int32))
+        idx.append(torch.where(r < k, r + o, Mk))   # on the device: no host round trip per image
         o += k
     dpe = _pe_rows(mae.encoder, mae.decoder_pos_embedding, dims)
-    x32 = GatherRowsFn.apply(table, torch.cat(idx).to(dev), dpe, Mk)   # ids_restore is a permutation: only the mask-token row repeats
+    x32 = GatherRowsFn.apply(table, torch.cat(idx).to(torch.int32), dpe, Mk)   # ids_restore is a permutation: only the mask-token row repeats
     cu = EG.cu_from_lens(lens, dev)
     H = mae.decoder.decoder_blocks.layers[0].self_attn.num_heads
     x32 = encoder_stack(mae.decoder.decoder_blocks, x32, cu, max(lens), H, prec, _wc(mae.decoder), training=mae.training)
