@@ -695,9 +695,11 @@ class ScheduledSamplingViTOMR(TeacherForcedViTOMR):
         img_latent = self.transition_head(img_latent)
         device = img_latent.device
         tf_input_seqs, target_seqs, lmx_attention_mask = batchify_and_split_lmx_seqs(lmx_seqs, self.decoder.pad_idx, device)
-        tf_pred_logits = self.decoder(tf_input_seqs, img_latent, lmx_attention_mask, latent_attention_mask)
-        mixed = self.sample_and_mix_seqs(teacher_forcing_prob, tf_input_seqs, tf_pred_logits, sample_tau, use_hard_sampling, device)
-        pred = self.decoder(mixed, img_latent, lmx_attention_mask, latent_attention_mask, token_idxs_input=False)
+        from ..train.autograd_path import shared_cross_kv
+        with shared_cross_kv():   # both passes attend to the same latent: its packed form and cross K/V projections are computed once
+            tf_pred_logits = self.decoder(tf_input_seqs, img_latent, lmx_attention_mask, latent_attention_mask)
+            mixed = self.sample_and_mix_seqs(teacher_forcing_prob, tf_input_seqs, tf_pred_logits, sample_tau, use_hard_sampling, device)
+            pred = self.decoder(mixed, img_latent, lmx_attention_mask, latent_attention_mask, token_idxs_input=False)
         return pred, target_seqs
 
     def forward_eval(self, x):

@@ -655,6 +655,26 @@ def ce_loss(pred, target_seqs, pad_idx):
 
 
 # ---- teacher-forced decoder (models.py:445-483) ---------------------------------------------------------------------------------
+_KV_SHARE = None   # set by shared_cross_kv(): {id(img_latent): {"mem": (mem32, lens_s, memc), "kv": {layer: kv}}}
+
+
+class shared_cross_kv:
+    """Context: decoder passes over the SAME image latent inside it share the packed memory and its per-layer cross K/V projections
+    (ScheduledSamplingViTOMR.forward_train runs the decoder twice on one latent, models.py:820-838: the reference recomputes the 12
+    memory projections - 65536 x 1024 x 2048 each at config 3 - in the second pass, forward and backward).  Gradients of both passes
+    meet on the shared tensors, so the result is the reference's up to summation order."""
+
+    def __enter__(self):
+        global _KV_SHARE
+        self._prev, _KV_SHARE = _KV_SHARE, {}
+        return self
+
+    def __exit__(self, *exc):
+        global _KV_SHARE
+        _KV_SHARE = self._prev
+        return False
+
+
 def decoder_forward(dec, input_seqs, img_latent, lmx_attention_mask, latent_attention_mask, token_idxs_input=True):
     _check_dropout(dec)
     prec, wc = _prec(), _wc(dec)
@@ -663,7 +683,12 @@ def decoder_forward(dec, input_seqs, img_latent, lmx_attention_mask, latent_atte
     dh = E // H
     B, T = input_seqs.shape[0], input_seqs.shape[1]
     lens_t = [T] * B if lmx_attention_mask is None else (~lmx_attention_mask).sum(dim=1).tolist()
-    mem32, lens_s = unpad_rows(img_latent.to(dev), latent_attention_mask)
+    share = None if _KV_SHARE is None else _KV_SHARE.setdefault((id(img_latent), id(latent_attention_mask), prec), {"kv": {}})
+    if share is not None and "mem" in share:
+        mem32, lens_s, memc_shared = share["mem"]
+    else:
+        mem32, lens_s = unpad_rows(img_latent.to(dev), latent_attention_mask)
+        memc_shared = None
     pos_idx = torch.cat([torch.arange(t, dtype=torch.int32) for t in lens_t]).to(dev)
     pos = GatherRowsFn.apply(dec.pos_embedding, pos_idx, None)
     if token_idxs_input:
@@ -673,16 +698,22 @@ def decoder_forward(dec, input_seqs, img_latent, lmx_attention_mask, latent_atte
         idx = torch.cat([torch.arange(b * T, b * T + l, dtype=torch.int32) for b, l in enumerate(lens_t)]).to(dev)
         x32 = GatherRowsFn.apply(input_seqs.reshape(B * T, E).float(), idx, pos)
     cu_t, cu_s = EG.cu_from_lens(lens_t, dev), EG.cu_from_lens(lens_s, dev)
-    memc = CastBf16Fn.apply(mem32) if bf else mem32
+    memc = memc_shared if memc_shared is not None else (CastBf16Fn.apply(mem32) if bf else mem32)
+    if share is not None:
+        share["mem"] = (mem32, lens_s, memc)
     mt, ms = max(lens_t), max(lens_s)
-    for ly in dec.decoder_blocks.layers:
+    for li, ly in enumerate(dec.decoder_blocks.layers):
         sa, ca = ly.self_attn, ly.multihead_attn
         tr = dec.training
         y = _self_attn_block(x32, sa, cu_t, H, mt, True, _p_of(sa, tr), _p_of(ly.dropout1, tr), prec, wc)
         x32 = LayerNormFn.apply(y, ly.norm1.weight, ly.norm1.bias, ly.norm1.eps)
         xc = CastBf16Fn.apply(x32) if bf else x32
         q = LinearFn.apply(xc, ca.in_proj_weight[:E], ca.in_proj_bias[:E], None, prec, _SliceCache(wc, ca, 0, E), False)
-        kv = LinearFn.apply(memc, ca.in_proj_weight[E:], ca.in_proj_bias[E:], None, prec, _SliceCache(wc, ca, E, 3 * E), False)
+        kv = None if share is None else share["kv"].get(li)
+        if kv is None:
+            kv = LinearFn.apply(memc, ca.in_proj_weight[E:], ca.in_proj_bias[E:], None, prec, _SliceCache(wc, ca, E, 3 * E), False)
+            if share is not None:
+                share["kv"][li] = kv
         a = CrossAttnFn.apply(q, kv, cu_t, cu_s, H, dh, mt, ms, _p_of(ca, tr))
         y = _proj_residual(a, ca.out_proj.weight, ca.out_proj.bias, x32, _p_of(ly.dropout2, tr), prec, wc)
         x32 = LayerNormFn.apply(y, ly.norm2.weight, ly.norm2.bias, ly.norm2.eps)
