@@ -310,6 +310,9 @@ __device__ __forceinline__ void gemm_vec_epilogue(const GemmArgs &g, const f32x1
     const int lr = lane & 31, lh = lane >> 5;
     const int ldc_e = g.ldc, n_valid = g.N - (bn0 + wn * 64);
     const bool do_gelu = g.flags & ACAI_GEMM_GELU, do_round = g.flags & ACAI_GEMM_ROUND_BF16;
+    // The bf16 rounding on the way into LDS is skipped when the value goes straight to a bf16 store, which rounds the same number the same way
+    // (measured: no change in tile time -- the epilogue is a latency chain, not VALU issue).
+    const bool pre_round = do_round && (do_gelu || g.aux_mode != 0 || g.residual != nullptr || g.out_dtype != ACAI_BF16);
     auto finish = [&](f32x4 &v, int row, int col) {   // four consecutive columns of one row, after bias / rounding
         if (g.aux_mode == 2) {
             float a4[4];
@@ -354,7 +357,7 @@ __device__ __forceinline__ void gemm_vec_epilogue(const GemmArgs &g, const f32x1
             for (int e = 0; e < 16; ++e) {
                 if (NP == 2 && (e >> 3) != pass) continue;   // 16-row passes: registers 0..7 hold rows 0..15, 8..15 rows 16..31
                 float v = acc[i][j][e] + bv;
-                if (do_round) v = round_bf16(v);
+                if (pre_round) v = round_bf16(v);
                 stg[((e & 3) + 8 * ((e >> 2) & (NP == 2 ? 1 : 3)) + 4 * lh) * EP + j * 32 + lr] = v;
             }
         }
