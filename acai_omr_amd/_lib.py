@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libacai_omr_hip.so")
-SOURCES = ["gemm.hip", "elementwise.hip", "attn_varlen.hip", "attn_bwd.hip", "train.hip", "decode.hip"]
+SOURCES = ["gemm.hip", "elementwise.hip", "attn_varlen.hip", "attn_bwd.hip", "train.hip", "decode.hip", "resize.hip"]
 
 ACAI_F32, ACAI_BF16 = 0, 1
 GEMM_GELU, GEMM_ROUND_BF16 = 1, 2
@@ -54,6 +54,7 @@ _SIGNATURES = {
     "acai_cross_kv_prefill": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "acai_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "acai_resize_bicubic_aa": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "acai_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "acai_attn_varlen_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_uint32, c_void_p]),

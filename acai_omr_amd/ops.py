@@ -121,6 +121,20 @@ def patchify(img, P, out, row0):
     return n
 
 
+def resize_bicubic_aa(img, size, clamp01=False):
+    """img (C,H,W) fp32 on the GPU -> (C,OH,OW): bicubic, antialiased, align_corners=False (the float path of torchvision's resize that
+    DynamicResize / PatchDivisibleResize call, acai_omr/utils/utils.py:325-330,351-356); clamp01 fuses DynamicResize's clamp (:367)."""
+    _chk(img, "img", torch.float32)
+    assert img.dim() == 3 and img.is_contiguous()
+    C, H, W = img.shape
+    OH, OW = int(size[0]), int(size[1])
+    tmp = torch.empty(C, H, OW, dtype=torch.float32, device=img.device)
+    out = torch.empty(C, OH, OW, dtype=torch.float32, device=img.device)
+    _lib.check(_lib.lib().acai_resize_bicubic_aa(img.data_ptr(), C, H, W, tmp.data_ptr(), out.data_ptr(), OH, OW, int(bool(clamp01)), _st()),
+               "acai_resize_bicubic_aa")
+    return out
+
+
 def gather_rows(table, idx, add=None, out=None):
     _chk(table, "table", torch.float32), _chk(idx, "idx", torch.int32)
     assert table.dim() == 2 and table.is_contiguous() and idx.dim() == 1 and idx.is_contiguous()

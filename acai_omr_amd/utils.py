@@ -1,6 +1,10 @@
 """Host-side helpers the callers on either side of the hot path use: the detokenise edge of inference and
 the learning-rate schedules of the two training loops.  Pure Python / stock torch schedulers; they drive `optim.FusedAdamW` exactly as they
-drive `torch.optim.AdamW` (only `param_groups[i]["lr"]` changes)."""
+drive `torch.optim.AdamW` (only `param_groups[i]["lr"]` changes); and the image-side resize transforms (8f-2), whose arithmetic runs in a HIP
+kernel."""
+import math
+
+import torch
 from torch.optim.lr_scheduler import CosineAnnealingLR, LinearLR, SequentialLR
 
 from .config import LMX_EOS_TOKEN
@@ -38,3 +42,81 @@ def cosine_anneal_with_warmup(optimizer, warmup_epochs, total_epochs, final_lr, 
 def ragged_collate_fn(batch):
     """DataLoader collate for ragged (image, target) examples: the model layer packs them itself (utils.py:225-229)."""
     return list(batch)
+
+
+# ---- image-side transforms (SURVEY 8f-2) ------------------------------------------------------------------------------------------------
+def dynamic_resize_target(height, width, patch_size, max_seq_len):
+    """Target (height, width) of `DynamicResize.forward` (acai_omr/utils/utils.py:343-349): integer aspect ratio (floor division), the short
+    side = patch_size * floor(sqrt(max_seq_len / aspect)), the long side = short * aspect."""
+    if width > height:
+        aspect_ratio = width // height
+        target_height = patch_size * math.floor(math.sqrt(max_seq_len / aspect_ratio))
+        target_width = target_height * aspect_ratio
+    else:
+        aspect_ratio = height // width
+        target_width = patch_size * math.floor(math.sqrt(max_seq_len / aspect_ratio))
+        target_height = target_width * aspect_ratio
+    return target_height, target_width
+
+
+def _center_crop(img, out_h, out_w):
+    """torchvision `center_crop` for an image at least as large as the crop (the only case DynamicResize reaches, utils.py:360-364):
+    top = round((H - out_h) / 2), left = round((W - out_w) / 2) (Python banker's rounding, as torchvision computes them)."""
+    h, w = img.shape[-2], img.shape[-1]
+    if out_h > h or out_w > w:
+        raise ValueError("center crop larger than the image")
+    top, left = int(round((h - out_h) / 2.0)), int(round((w - out_w) / 2.0))
+    return img[..., top:top + out_h, left:left + out_w]
+
+
+def _device_image(img):
+    if not torch.is_tensor(img) or img.dim() != 3:
+        raise TypeError("expected a C x H x W tensor (decode PIL images with ToImage / ToDtype first, as the reference pipelines do)")
+    if not torch.cuda.is_available():
+        raise RuntimeError("acai_omr_amd transforms run on the GPU (HIP resize kernel); there is no CPU fallback")
+    return img.to(device="cuda", dtype=torch.float32).contiguous()
+
+
+class PatchDivisibleResize(torch.nn.Module):
+    """`PatchDivisibleResize` (acai_omr/utils/utils.py:309-330): resize to the nearest lower patch-divisible size, bicubic + antialias, on the GPU.
+    Takes a C x H x W tensor (CPU tensors are uploaded once); returns a GPU tensor."""
+
+    def __init__(self, patch_size):
+        super().__init__()
+        self.patch_size = patch_size
+
+    def forward(self, img):
+        from . import ops
+        img = _device_image(img)
+        _, h, w = img.shape
+        new_w = max(w // self.patch_size * self.patch_size, self.patch_size)
+        new_h = max(h // self.patch_size * self.patch_size, self.patch_size)
+        return ops.resize_bicubic_aa(img, (new_h, new_w))
+
+
+class DynamicResize(torch.nn.Module):
+    """`DynamicResize` (acai_omr/utils/utils.py:334-367): same constructor and the same arithmetic -- target size from the integer aspect ratio and
+    the sequence budget, bicubic antialiased resize, optional centre crop to the positional-embedding grid, clamp to [0, 1] -- with the resize and
+    the clamp in one HIP launch pair on the GPU.  Takes the float C x H x W tensor the reference's `ToImage -> ToDtype(float32, scale=True)`
+    produce (a CPU tensor is uploaded once; this replaces the per-example `.to(device)` of `pre_train.py:56`) and returns a GPU tensor."""
+
+    def __init__(self, patch_size, max_seq_len, pe_max_height, pe_max_width, crop_imgs):
+        super().__init__()
+        self.patch_size = patch_size
+        self.max_seq_len = max_seq_len
+        self.pe_max_height = pe_max_height
+        self.pe_max_width = pe_max_width
+        self.crop_imgs = crop_imgs
+
+    def forward(self, img):
+        from . import ops
+        img = _device_image(img)
+        target_height, target_width = dynamic_resize_target(img.shape[-2], img.shape[-1], self.patch_size, self.max_seq_len)
+        img = ops.resize_bicubic_aa(img, (target_height, target_width), clamp01=True)
+        if self.crop_imgs:
+            if target_height / self.patch_size > self.pe_max_height:
+                img = _center_crop(img, self.pe_max_height * self.patch_size, img.shape[-1])
+            if target_width / self.patch_size > self.pe_max_width:
+                img = _center_crop(img, img.shape[-2], self.pe_max_width * self.patch_size)
+            img = img.contiguous()
+        return img

@@ -75,6 +75,12 @@ int acai_cross_kv_prefill(const void *mem, int ldm, const void *Wkv, int ldw, co
  * rows are written starting at out + row0*ld (dtype `out_dtype`). */
 int acai_patchify(const float *img, int H, int W, int P, void *out, int ld, int row0, int out_dtype, void *stream);
 
+/* DynamicResize / PatchDivisibleResize resize step (acai_omr/utils/utils.py:325-330 `v2.Resize(...)`, :351-356 `F.resize(img, size,
+ * BICUBIC, antialias=True)` on a float32 C x H x W tensor = aten `_upsample_bicubic2d_aa`, align_corners = False), optionally followed by
+ * DynamicResize's `.clamp(0.0, 1.0)` (:367).  img [C][H][W] -> out [C][OH][OW], all fp32 contiguous; tmp holds C*H*OW floats (the
+ * width pass).  C*H, OH and C <= 65535. */
+int acai_resize_bicubic_aa(const float *img, int C, int H, int W, float *tmp, float *out, int OH, int OW, int clamp01, void *stream);
+
 /* out[i,:] = table[idx[i],:] (+ add[i,:]) : pos_embedding slices (M:50), nn.Embedding (M:460),
  * MAE shuffle / restore index_select (M:114,123,229). table/out fp32. */
 int acai_gather_rows(const float *table, const int32_t *idx, const float *add, float *out, int rows, int dim, void *stream);

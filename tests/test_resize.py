@@ -1,0 +1,114 @@
+"""the resize transforms.  CPU: the numpy oracle against aten's own `_upsample_bicubic2d_aa` (what torchvision's float resize
+calls) and DynamicResize's size arithmetic; GPU: the HIP kernel and the `DynamicResize` / `PatchDivisibleResize` mirrors against both."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import resize_oracle
+
+SIZES = [((1, 37, 53), (16, 32)), ((1, 64, 200), (64, 256)), ((3, 50, 41), (75, 90)), ((1, 90, 300), (32, 96)), ((1, 33, 33), (33, 33)),
+         ((1, 7, 500), (16, 16)), ((1, 120, 17), (16, 64))]
+
+
+def _aten(img, size):
+    return torch.nn.functional.interpolate(img[None], size=size, mode="bicubic", align_corners=False, antialias=True)[0]
+
+
+@pytest.mark.parametrize("shape,size", SIZES)
+def test_oracle_matches_aten(shape, size):
+    g = torch.Generator().manual_seed(sum(shape) + sum(size))
+    img = torch.rand(*shape, generator=g)
+    ref = _aten(img, size).numpy()
+    got = resize_oracle.resize_bicubic_aa(img.numpy(), size)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 2e-6
+
+
+def test_dynamic_resize_target_sizes():
+    from acai_omr_amd.utils import dynamic_resize_target
+    # utils.py:343-349 by hand: 4:1 system -> aspect 4, 16 * floor(sqrt(1024 / 4)) = 256 high, 1024 wide
+    assert dynamic_resize_target(500, 2000, 16, 1024) == (256, 1024)
+    assert dynamic_resize_target(500, 2400, 16, 1024) == (256, 1024)          # 2400 // 500 = 4: the ratio is floored
+    assert dynamic_resize_target(700, 700, 16, 1024) == (512, 512)            # square goes through the else branch
+    assert dynamic_resize_target(3000, 1000, 16, 1024) == (16 * 18 * 3, 16 * 18)
+    assert dynamic_resize_target(600, 1000, 16, 4096) == (1024, 1024)         # 1000 // 600 = 1
+    for (h, w) in [(480, 1999), (1200, 333), (64, 64)]:
+        th, tw = dynamic_resize_target(h, w, 16, 1024)
+        assert th % 16 == 0 and tw % 16 == 0 and (th // 16) * (tw // 16) <= 1024
+
+
+def test_transforms_refuse_without_gpu():
+    from acai_omr_amd.utils import DynamicResize
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        DynamicResize(16, 1024, 60, 200, False)(torch.rand(1, 40, 160))
+    with pytest.raises(TypeError):
+        DynamicResize(16, 1024, 60, 200, False)("not a tensor")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from acai_omr_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,size", SIZES + [((1, 1400, 5000), (512, 2048)), ((1, 300, 1100), (512, 2048))])
+def test_hip_resize_matches_aten_and_oracle(dev, shape, size):
+    from acai_omr_amd import ops
+    g = torch.Generator().manual_seed(sum(shape) + sum(size))
+    img = torch.rand(*shape, generator=g)
+    got = ops.resize_bicubic_aa(img.to(dev), size).cpu()
+    ref = _aten(img, size)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max() < 2e-6          # fp32; the two differ only in fused multiply-adds
+    if shape[1] * shape[2] <= 64 * 200:
+        assert np.abs(got.numpy() - resize_oracle.resize_bicubic_aa(img.numpy(), size)).max() < 2e-6
+    clamped = ops.resize_bicubic_aa(img.to(dev), size, clamp01=True).cpu()
+    assert torch.equal(clamped, got.clamp(0.0, 1.0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw,crop", [((300, 1250), False), ((1250, 300), False), ((90, 4000), True), ((4000, 90), True), ((333, 333), True)])
+def test_dynamic_resize_mirror(dev, hw, crop):
+    """End to end against the oracle's restatement of utils.py:343-367 and against aten for the resize itself; bicubic overshoot is clamped; the
+    wide / tall cases exceed the 60 x 200 positional grid and are centre-cropped."""
+    from acai_omr_amd.utils import DynamicResize
+    g = torch.Generator().manual_seed(hw[0] + hw[1])
+    img = (torch.rand(1, *hw, generator=g) > 0.5).float()     # black / white: overshoots on both sides
+    t = DynamicResize(16, 1024 if not crop else 4096, 60, 200, crop)
+    out = t(img)                                              # CPU tensor in, GPU tensor out
+    assert out.is_cuda and out.is_contiguous()
+    ref = resize_oracle.dynamic_resize(img.numpy(), 16, t.max_seq_len, 60, 200, crop)
+    assert tuple(out.shape) == ref.shape
+    assert out.shape[-2] % 16 == 0 and out.shape[-1] % 16 == 0
+    if crop:
+        assert out.shape[-2] // 16 <= 60 and out.shape[-1] // 16 <= 200
+    assert np.abs(out.cpu().numpy() - ref).max() < 2e-6
+    assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+    assert torch.equal(t(img.to(dev)), out)                   # device tensor in: same result
+
+
+@pytest.mark.gpu
+def test_patch_divisible_resize_mirror(dev):
+    from acai_omr_amd.utils import PatchDivisibleResize
+    img = torch.rand(1, 123, 457, generator=torch.Generator().manual_seed(5))
+    out = PatchDivisibleResize(16)(img)
+    assert tuple(out.shape) == (1, 112, 448)
+    assert (out.cpu() - _aten(img, (112, 448))).abs().max() < 2e-6
+    assert tuple(PatchDivisibleResize(16)(torch.rand(1, 9, 40)).shape) == (1, 16, 32)   # floor would be 0: minimum one patch
+
+
+@pytest.mark.gpu
+def test_resized_image_feeds_the_encoder(dev):
+    """The transform's output is what the encoder's batchify takes: patch-divisible, inside the positional grid, on the device."""
+    from acai_omr_amd.utils import DynamicResize
+    img = torch.rand(1, 500, 2100, generator=torch.Generator().manual_seed(9))
+    out = DynamicResize(16, 1024, 60, 200, False)(img)
+    assert tuple(out.shape) == (1, 256, 1024)
