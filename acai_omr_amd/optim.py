@@ -15,6 +15,22 @@ from . import _lib
 CHUNK = 16384  # elements per workgroup
 
 
+def _mark_modified(tensors):
+    """The kernel writes the parameters behind autograd's back: bump their version counters, so that everything keyed on `_version` sees the
+    write - `engine.WeightCache` (bf16 / transposed operand copies, refreshed once per optimizer step) and autograd's saved-tensor check."""
+    tensors = list(tensors)
+    bump = getattr(torch._C._autograd, "_unsafe_set_version_counter", None)
+    if bump is not None:
+        try:
+            bump(tuple(tensors), tuple(t._version + 1 for t in tensors))
+            return
+        except TypeError:   # older signature
+            pass
+    torch._foreach_add_(tensors, 0)   # an in-place no-op moves the counters too
+
+
+
+
 class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, maximize=False):
         if amsgrad or maximize:
@@ -88,4 +104,5 @@ class FusedAdamW(torch.optim.Optimizer):
             st_ = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             _lib.check(_lib.lib().acai_adamw_step(tdev.data_ptr(), gdev.data_ptr(), ctd.data_ptr(), cod.data_ptr(), n_chunks, CHUNK, float(grad_scale), st_),
                        "acai_adamw_step")
+        _mark_modified(p for _, p, _ in active)
         return loss
