@@ -41,7 +41,7 @@ struct SkinnyArgs {
     const float *rln_w, *rln_b, *rstats;
     int x_bf16, y_bf16;      // activation in / out stored as bf16 (x: row stride ldx in bf16 elements)
     int rows_per_block;      // MFMA kernel: weight rows per workgroup (set by the launcher)
-    int ablate;              // diagnostics only (ACAI_SKINNY_ABLATE): 1 = no weight loads, 2 = no activation loads, 4 = no MFMA
+    int w_cached;            // non-zero: default-policy (cacheable) weight loads instead of non-temporal ones (ACAI_SKINNY_NT, an A/B aid)
 };
 
 template <typename TW, bool FAST>
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
     const int n0 = blockIdx.x * R;
     const int K = a.K, Kw = K / NW, kbase = wave * Kw, nch = Kw >> 5;
     const int pitch = K * 2 + 16;
-    const bool row_ok = r < R && n0 + r < a.N && !(a.ablate & 1);
+    const bool row_ok = r < R && n0 + r < a.N;
     const bf16_t *Wrow = reinterpret_cast<const bf16_t *>(a.W) + (size_t)(row_ok ? n0 + r : 0) * a.ldw + kbase + 8 * q;
     float *red = reinterpret_cast<float *>(smem);              // [NW][256] floats
     unsigned char *xs = smem + NW * 1024;                      // [rows][pitch] bf16 activation image
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 wf[c] = make_uint4(0, 0, 0, 0);
-                if (c < nch && row_ok) wf[c] = (a.ablate & 8) ? *reinterpret_cast<const uint4 *>(Wrow + 32 * c) : ld_nt16(Wrow + 32 * c);
+                if (c < nch && row_ok) wf[c] = a.w_cached ? *reinterpret_cast<const uint4 *>(Wrow + 32 * c) : ld_nt16(Wrow + 32 * c);
             }
         };
         constexpr bool X_FIRST = !XBF16 && NV <= 4;   // (the bf16-input and NV = 16 paths keep weights first)
@@ -231,8 +231,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
             request_epilogue();
         }
         // 2. activation image: wave w takes rows w, w+4 (together), then w+8, w+12; lane takes 4-element groups
-        if (a.ablate & 2) {
-        } else if constexpr (XBF16) {
+        if constexpr (XBF16) {
             // plain copy of the bf16 rows (global loads and LDS stores do not alias: the compiler hoists the loads of a row)
             for (int b0 = wave; b0 < nb; b0 += NW) {
                 const bf16_t *xr0 = reinterpret_cast<const bf16_t *>(a.x) + (size_t)(bt + b0) * a.ldx;
@@ -346,11 +345,11 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
             for (int c = 0; c < 8; ++c) {  // next batch of weight fragments (none when NW covers K in one batch)
                 wn[c] = make_uint4(0, 0, 0, 0);
                 if constexpr (NW * 256 < SKM_MAXK)
-                    if (c0 + 8 + c < nch && row_ok) wn[c] = (a.ablate & 8) ? *reinterpret_cast<const uint4 *>(Wrow + 32 * (c0 + 8 + c)) : ld_nt16(Wrow + 32 * (c0 + 8 + c));
+                    if (c0 + 8 + c < nch && row_ok) wn[c] = a.w_cached ? *reinterpret_cast<const uint4 *>(Wrow + 32 * (c0 + 8 + c)) : ld_nt16(Wrow + 32 * (c0 + 8 + c));
             }
 #pragma unroll
             for (int c = 0; c < 8; ++c)
-                if (c0 + c < nch && !(a.ablate & 4)) {
+                if (c0 + c < nch) {
                     const uint4 xf = *reinterpret_cast<const uint4 *>(xfrag + 64 * (c0 + c));
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[c]), __builtin_bit_cast(bf16x8, xf), acc, 0, 0, 0);
                 }
@@ -416,13 +415,12 @@ int launch_skinny(const SkinnyArgs &a, hipStream_t st) {
             // one CU ingests only ~25 GB/s from HBM: spread a small weight matrix over >= ~200 workgroups by giving each
             // fewer than 16 rows (the unused MFMA rows load nothing)
             SkinnyArgs b = a;
-            static const int abl = getenv("ACAI_SKINNY_ABLATE") ? atoi(getenv("ACAI_SKINNY_ABLATE")) : 0;
             static const int rpb = getenv("ACAI_SKINNY_ROWS") ? atoi(getenv("ACAI_SKINNY_ROWS")) : 0;
-            b.ablate = abl;
+            b.w_cached = 0;
             // weight cache policy (A/B aid): 0 = default-policy loads for every matrix, 2 = default policy below 8 MB (candidates for the
             // Infinity Cache across steps) and non-temporal above, unset = non-temporal everywhere
             static const int ntm = getenv("ACAI_SKINNY_NT") ? atoi(getenv("ACAI_SKINNY_NT")) : 1;
-            if (ntm == 0 || (ntm == 2 && (size_t)a.N * a.K * 2 < (8u << 20))) b.ablate |= 8;
+            if (ntm == 0 || (ntm == 2 && (size_t)a.N * a.K * 2 < (8u << 20))) b.w_cached = 1;
             b.rows_per_block = rpb ? rpb : (a.N >= 2560 ? 16 : (a.N >= 1600 ? 8 : 4));
             // (the K = 4096 form holds a 131 KB activation image: one workgroup per CU, so its batch tiles stay a loop inside the workgroup)
             const dim3 grid(cdiv(a.N, b.rows_per_block), wide ? 1 : cdiv(a.B, 16));
