@@ -545,6 +545,11 @@ class GRPOViTOMR(ViTOMR):
             converted[new] = teacher_forced_state_dict[name]
         return converted
 
+    def create_rollout_mask(self, rollouts):
+        """Name the reference's own tests use (tests/test_vitomr.py:438-442) for the mask `cached_forward_rollout_policy` returns: True up to
+        and including each row's first <eos> - the same rule as `create_inference_mask`."""
+        return self.create_inference_mask(rollouts)
+
     def expand_img_latent_for_rollout(self, img_latent, latent_attention_mask, group_size):
         img_latent = img_latent.unsqueeze(1).expand(-1, group_size, -1, -1).flatten(start_dim=0, end_dim=1)
         latent_attention_mask = latent_attention_mask.unsqueeze(1).expand(-1, group_size, -1).flatten(start_dim=0, end_dim=1)

@@ -127,3 +127,40 @@ def test_host_helpers_stringify_and_schedules():
                  lambda o: stepwise_cosine_anneal_with_warmup(o, 3, 2, 1e-6, 6)):
         a, b = lrs(torch.optim.AdamW, make), lrs(FusedAdamW, make)
         assert a == b and a[0][0] == 1e-3 * 5e-3 and max(x[0] for x in a) <= 1e-3 + 1e-12
+
+
+def test_grpo_host_helpers_reference_vectors():
+    """Known answers of the reference's tests/test_vitomr.py for the GRPO helpers around the rollout decode (rollout masks :414-442, rollout
+    preparation :457-497, latent expansion :395-412, state-dict conversion + freezing :376-393) - host logic, no kernels."""
+    import torch
+    from conftest import VOCAB
+    from acai_omr_amd.models.models import FineTuneOMREncoder, GRPOViTOMR, OMRDecoder, TeacherForcedViTOMR
+    kw = dict(num_layers=2, num_heads=1, hidden_dim=10, mlp_dim=1)
+    torch.manual_seed(0)
+    tf = TeacherForcedViTOMR(FineTuneOMREncoder(16, 60, 200, 1, **kw), None, OMRDecoder(1536, VOCAB, **kw))
+    g = GRPOViTOMR(tf.encoder, tf.transition_head, tf.decoder, tf.state_dict())
+    assert all(not p.requires_grad for p in g.encoder.parameters()) and all(not p.requires_grad for p in g.transition_head.parameters())
+    assert all(p.requires_grad for p in g.decoder.parameters())
+    assert all(m.p == 0.0 for m in g.encoder.modules() if isinstance(m, torch.nn.Dropout))
+    # one encoder stack again: frozen layer 0 + fine-tuned layer 0 -> encoder_blocks.layers.{0,1}
+    assert torch.equal(g.encoder.encoder_blocks.layers[0].linear1.weight, tf.encoder.frozen_blocks.layers[0].linear1.weight)
+    assert torch.equal(g.encoder.encoder_blocks.layers[1].linear1.weight, tf.encoder.fine_tune_blocks.layers[0].linear1.weight)
+    bos, eos, pad = g.decoder.bos_idx, g.decoder.eos_idx, g.decoder.pad_idx
+    T, F = True, False
+    cases = [([[bos, 10, 10, eos], [bos, 20, 20, eos]], [[T] * 4, [T] * 4]),
+             ([[bos, eos, 10, eos], [bos, 20, 20, eos]], [[T, T, F, F], [T] * 4]),
+             ([[bos, 10, 10, 10], [bos, 20, 20, 20]], [[T] * 4, [T] * 4]),
+             ([[bos, 20, 20, 20], [bos, eos, 10, 10]], [[T] * 4, [T, T, F, F]])]
+    for rollouts, expected in cases:
+        assert torch.equal(g.create_rollout_mask(torch.tensor(rollouts)), torch.tensor(expected))
+    prep = [([[bos, 10, 10, eos], [bos, 10, 10, eos]], [[F] * 3, [F] * 3]),
+            ([[bos, 10, 10, eos], [bos, eos, pad, pad]], [[F] * 3, [F, T, T]]),
+            ([[bos, 10, eos, pad], [bos, 10, 10, 10]], [[F, F, T], [F] * 3])]
+    for rollouts, expected in prep:
+        r = torch.tensor(rollouts)
+        out, mask = g.prepare_rollouts_for_policy_theta(r, g.create_rollout_mask(r))
+        assert torch.equal(out, r[:, :-1]) and torch.equal(mask, torch.tensor(expected))
+    lat = torch.arange(2 * 3 * 10, dtype=torch.float32).view(2, 3, 10)
+    msk = torch.tensor([[F, F, T], [F, F, F]])
+    lx, mx = g.expand_img_latent_for_rollout(lat, msk, 2)
+    assert torch.equal(lx, torch.cat([lat[:1].repeat(2, 1, 1), lat[1:].repeat(2, 1, 1)])) and torch.equal(mx, torch.cat([msk[:1].repeat(2, 1), msk[1:].repeat(2, 1)]))

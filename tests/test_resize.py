@@ -39,6 +39,16 @@ def test_dynamic_resize_target_sizes():
         assert th % 16 == 0 and tw % 16 == 0 and (th // 16) * (tw // 16) <= 1024
 
 
+def test_dynamic_resize_reference_cases_sizes():
+    """The three cases of the reference's tests/test_datasets.py:127-141 (patch 2, budget 10, grid 4 x 8), on the size arithmetic."""
+    from acai_omr_amd.utils import dynamic_resize_target
+    for hw in [(6, 10), (10, 6)]:
+        th, tw = dynamic_resize_target(*hw, 2, 10)
+        assert (tw / 2) * (th / 2) <= 10
+    th, tw = dynamic_resize_target(100, 200, 2, 10)
+    assert tw / 2 < 8 and th / 2 < 4
+
+
 def test_transforms_refuse_without_gpu():
     from acai_omr_amd.utils import DynamicResize
     if torch.cuda.is_available():
@@ -93,6 +103,18 @@ def test_dynamic_resize_mirror(dev, hw, crop):
     assert np.abs(out.cpu().numpy() - ref).max() < 2e-6
     assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0
     assert torch.equal(t(img.to(dev)), out)                   # device tensor in: same result
+
+
+@pytest.mark.gpu
+def test_dynamic_resize_reference_cases(dev):
+    """tests/test_datasets.py:127-141 through the transform itself."""
+    from acai_omr_amd.utils import DynamicResize
+    resize = DynamicResize(2, 10, 4, 8, False)
+    for shape in [(1, 6, 10), (1, 10, 6)]:
+        img = resize(torch.rand(*shape))
+        assert (img.shape[-1] / 2) * (img.shape[-2] / 2) <= 10
+    img = resize(torch.rand(1, 100, 200))
+    assert img.shape[-1] / 2 < 8 and img.shape[-2] / 2 < 4
 
 
 @pytest.mark.gpu

@@ -38,6 +38,10 @@ def test_prepare_lmx_sequence_and_constants():
     assert ids.dtype == torch.int64 and ids.tolist() == [0] + [dec.tokens_to_idxs[w] for w in words] + [2]
     with pytest.raises(KeyError):
         prep("no-such-token")
+    # the reference's known answers (tests/test_omr_teacher_force_train.py:22-28), on the full vocabulary
+    full = loops.PrepareLMXSequence(OMRDecoder(1, VOCAB, num_layers=1, hidden_dim=16, num_heads=2, mlp_dim=16).tokens_to_idxs)
+    assert full("measure key:fifths:-7 time").tolist() == [0, 3, 4, 19, 2]
+    assert full("tremolo:4 C1").tolist() == [0, 226, 66, 2]
     # pre_train.py:27-36, omr_teacher_force_train.py:30-57
     assert loops.PRETRAIN == dict(epochs=500, checkpoint_freq=50, base_lr=1.5e-4, min_lr=1e-6, betas=(0.9, 0.95), weight_decay=0.05, warmup_epochs=50,
                                   batch_size=64)
