@@ -467,3 +467,42 @@ def test_full_size_teacher_forced_step_vs_oracle(dev):
         assert md(params[name].grad, gref) < 3e-4 * max(1.0, float(gref.abs().max())), name
         checked += 1
     assert checked >= 8
+
+
+@pytest.mark.parametrize("ft_depth", [1, 2])
+def test_fine_tune_freezing_and_llrd_like_reference(dev, ft_depth):
+    """The behaviour the reference's tests/test_vitomr.py:203-338 pin (partial fine-tune, LLRD param groups), on its odd debug widths
+    (hidden 10, one head of d_h = 10, mlp 1): after one optimizer step over `create_fine_tune_param_groups`, every decoder / transition-head /
+    fine-tuned parameter has moved and every frozen one is bit-identical; with a partial fine-tune the patch projection and the positional
+    embedding are frozen too, with a full one they train; every trainable parameter sits in exactly one group, decoder and head at the base
+    LR, encoder groups at or below the fine-tune LR."""
+    from acai_omr_amd.models.models import FineTuneOMREncoder, OMRCELoss, OMRDecoder, TeacherForcedViTOMR
+    kw = dict(num_layers=2, num_heads=1, hidden_dim=10, mlp_dim=1)
+    torch.manual_seed(3)
+    m = TeacherForcedViTOMR(FineTuneOMREncoder(16, 60, 200, ft_depth, **kw), None, OMRDecoder(1536, VOCAB, **kw)).to(dev).train()
+    groups, _ = m.create_fine_tune_param_groups(100.0, 50.0, 0.99)
+    groups = [{"params": list(g["params"]), "lr": g["lr"]} for g in groups]
+    lr_of = {}
+    for g in groups:
+        for p in g["params"]:
+            assert id(p) not in lr_of
+            lr_of[id(p)] = g["lr"]
+    for name, p in m.named_parameters():
+        if p.requires_grad:
+            assert id(p) in lr_of, name
+            assert lr_of[id(p)] == 100.0 if ("decoder" in name or "transition" in name) else lr_of[id(p)] <= 50.0, name
+    opt = torch.optim.SGD([g for g in groups if g["params"]])
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    g = torch.Generator().manual_seed(4)
+    x = [(torch.rand(1, 64, 128, generator=g).to(dev), torch.randint(0, 227, (8,), generator=g).to(dev)),
+         (torch.rand(1, 32, 32, generator=g).to(dev), torch.randint(0, 227, (6,), generator=g).to(dev))]
+    pred, target = m(x)
+    assert pred.shape == torch.Size([2, 7, 227])
+    OMRCELoss(m.decoder.pad_idx)(pred, target).backward()
+    opt.step()
+    for name, p in m.named_parameters():
+        moved = not torch.equal(p.detach(), before[name])
+        if "frozen" in name or (ft_depth == 1 and ("pos_embedding" in name and "decoder" not in name or "projection" in name)):
+            assert not p.requires_grad and not moved, name
+        elif any(k in name for k in ("decoder", "fine_tune", "transition_head")) or ft_depth == 2:
+            assert p.requires_grad and moved, name
