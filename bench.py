@@ -247,7 +247,10 @@ def main():
 
     mae_res = None
     if not a.no_mae:
-        mae_res = bench_mae(dev, rank, world, dist, a.mae_batch, a.height, a.width, a.mae_steps, a.mae_dtype)
+        try:
+            mae_res = bench_mae(dev, rank, world, dist, a.mae_batch, a.height, a.width, a.mae_steps, a.mae_dtype)
+        except Exception as e:   # the secondary leg must not cost the headline line (every rank runs the same code: an error is symmetric)
+            mae_res = dict(error=f"{type(e).__name__}: {e}")
 
     out = None
     if rank == 0:
