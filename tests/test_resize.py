@@ -9,7 +9,7 @@ import torch
 from oracle import resize_oracle
 
 SIZES = [((1, 37, 53), (16, 32)), ((1, 64, 200), (64, 256)), ((3, 50, 41), (75, 90)), ((1, 90, 300), (32, 96)), ((1, 33, 33), (33, 33)),
-         ((1, 7, 500), (16, 16)), ((1, 120, 17), (16, 64))]
+         ((1, 7, 500), (16, 16)), ((1, 120, 17), (16, 64)), ((1, 1, 1), (4, 4)), ((1, 2, 3), (7, 5)), ((2, 5, 1), (3, 9)), ((1, 40, 40), (1, 1))]
 
 
 def _aten(img, size):
