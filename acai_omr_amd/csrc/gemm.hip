@@ -1072,7 +1072,13 @@ int launch(const GemmArgs &g, hipStream_t st) {
         // three-stage 256x128 kernel; small problems keep two 128x128 workgroups per CU.
         const int ktiles = g.K / BKG;
         // (fp32: the 256x256 tile never beats the three-stage kernel - 102 against 137 TF at 32768 x 768 x 3072 - and a K-tile is 32 floats)
-        if (v == 0) v = nwg4 >= 512 ? (ktiles <= 24 ? 4 : (sizeof(T) == 2 && ktiles >= 64 && nwg256 >= n_cu ? 5 : 3)) : 1;
+        // The 256x256 tile only when its tiles fill whole rounds of the chip (260 tiles on 256 CUs are two rounds: 16416 x 1024 x 4096 took
+        // 240 us on it against 170 us on the 128x128 kernel, tools/bench_gemm_tf.py); long-K problems of only a few rounds then go to the
+        // 128x128 kernel, whose two co-resident workgroups cover each other (170 against 192 us for the three-stage tile there).
+        const int rounds256 = cdiv(nwg256, n_cu);
+        const bool fills256 = nwg256 >= n_cu && nwg256 * 100 >= rounds256 * n_cu * 85;
+        if (v == 0)
+            v = nwg4 >= 512 ? (ktiles <= 24 ? 4 : (sizeof(T) == 2 && ktiles >= 64 ? (fills256 ? 5 : (nwg4 < 4 * n_cu ? 1 : 3)) : 3)) : 1;
         if (v == 5 && nwg256 < 8) v = 1;
         if (v == 4 && nwg4 < 8) v = 1;
         switch (v) {
