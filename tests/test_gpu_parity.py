@@ -523,3 +523,49 @@ def test_decode_is_deterministic_run_to_run(dev):
             outs.append((seqs.clone(), lps.clone()))
     for o in outs[1:]:
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+
+
+def test_full_size_batch_independence_of_decode(dev):
+    """Size-independent property at the BASELINE configuration (8 sequences, 4096-patch memories, full-size decoder): a sequence decoded inside
+    the batch of 8 gets the tokens and log-probs it gets when decoded alone (fp32 path: different cross-attention split counts and GEMV batch
+    tiles may only move results by rounding noise)."""
+    from acai_omr_amd.models.models import OMRDecoder, ViTOMR
+    torch.manual_seed(13)
+    dec = OMRDecoder(96, VOCAB, num_layers=12)
+    with torch.no_grad():
+        for n, p in dec.named_parameters():
+            if "norm" in n:
+                p.add_(0.1 * torch.randn_like(p))
+        dec.unembed.weight.mul_(6.0)
+    cached = dec.to_cached_version(8, torch.float)
+    cached.load_state_dict(dec.state_dict())
+    model = ViTOMR(None, None, cached.to(dev).eval())
+    S, steps = 4096, 40
+    g = torch.Generator().manual_seed(14)
+    mem = torch.randn(8 * S, 1024, generator=g).to(dev)
+    with torch.no_grad():
+        seqs, lps, mask = model._greedy_packed(mem, None, [S] * 8, steps)
+        for b in (0, 5):
+            s1, l1, m1 = model._greedy_packed(mem[b * S:(b + 1) * S].contiguous(), None, [S], steps)
+            n = s1.shape[1]
+            assert seqs.shape[1] >= n and torch.equal(s1[0], seqs[b, :n])   # the batch result is clipped to the longest row, hence >= n
+            assert (l1[0] - lps[b, :n]).abs().max() < 1e-4
+
+
+def test_full_size_batch_independence_of_mae(dev):
+    """The same property for the full-size MAE on 512 x 2048 images (BASELINE configuration 2): an image's predictions, loss mask and targets
+    do not depend on what else is in the ragged batch (same masking noise)."""
+    from acai_omr_amd.config import MASK_RATIO, PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH
+    from acai_omr_amd.models.models import MAE
+    torch.manual_seed(15)
+    mae = MAE(MASK_RATIO, PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH).to(dev).eval()
+    g = torch.Generator().manual_seed(16)
+    imgs = [torch.rand(1, 512, 2048, generator=g).to(dev), torch.rand(1, 256, 1024, generator=g).to(dev), torch.rand(1, 512, 2048, generator=g).to(dev)]
+    noises = [torch.rand((im.shape[-2] // PATCH_SIZE) * (im.shape[-1] // PATCH_SIZE), generator=g) for im in imgs]
+    with torch.no_grad():
+        pred, lm, tgt = mae([(im, im) for im in imgs], noises=noises)
+        for b in (0, 1):
+            p1, lm1, t1 = mae([(imgs[b], imgs[b])], noises=[noises[b]])
+            n = p1.shape[1]
+            assert torch.equal(lm1[0], lm[b, :n]) and torch.equal(t1[0], tgt[b, :n])
+            assert (p1[0] - pred[b, :n]).abs().max() < 2e-4
