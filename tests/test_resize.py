@@ -134,3 +134,19 @@ def test_resized_image_feeds_the_encoder(dev):
     img = torch.rand(1, 500, 2100, generator=torch.Generator().manual_seed(9))
     out = DynamicResize(16, 1024, 60, 200, False)(img)
     assert tuple(out.shape) == (1, 256, 1024)
+
+
+@pytest.mark.gpu
+def test_resize_properties_at_full_size(dev):
+    """Size-independent properties on a scan-sized input (1400 x 5000 -> 512 x 2048): a constant image stays that constant (every window's
+    weights sum to one), the map is linear, and the output stays inside the input's range up to the bicubic overshoot bound."""
+    from acai_omr_amd import ops
+    g = torch.Generator().manual_seed(31)
+    x, y = torch.rand(1, 1400, 5000, generator=g).to(dev), torch.rand(1, 1400, 5000, generator=g).to(dev)
+    size = (512, 2048)
+    c = ops.resize_bicubic_aa(torch.full((1, 1400, 5000), 0.625, device=dev), size)
+    assert (c - 0.625).abs().max() < 1e-6
+    rx, ry = ops.resize_bicubic_aa(x, size), ops.resize_bicubic_aa(y, size)
+    mix = ops.resize_bicubic_aa((0.25 * x + 3.0 * y).contiguous(), size)
+    assert (mix - (0.25 * rx + 3.0 * ry)).abs().max() < 2e-5
+    assert float(rx.min()) > -0.2 and float(rx.max()) < 1.2
