@@ -277,6 +277,12 @@ def main():
                    config=dict(workload=f"vitomr_greedy_decode batch {a.batch}/GPU of {a.height}x{a.width} images ({S} patches), decode steps {a.warmup + 1}..{a.warmup + a.steps}" + ("" if a.warmup + a.steps <= cap else f" (re-armed every {cap} steps)"),
                                batch_per_gpu=a.batch, memory_len=S, decoder="12 x d1024 h16 mlp4096, V=227", hipgraph=True),
                    prefill_ms=prefill_s * 1e3, prefill_encoder_dtype=a.encoder_dtype, roofline=roof, mae=mae_res)
+        # decode-only (`value`) and end to end.  Composed from the two measured parts - the prefill timed once above and the timed
+        # decode steps - for a generation of warmup + steps tokens per sequence; not a separately timed run.
+        gen = a.warmup + a.steps
+        out["end_to_end"] = dict(tokens_per_s=world * a.batch * gen / (prefill_s + gen * dt / a.steps), generated_tokens_per_sequence=gen,
+                                 includes="encoder (fp32) + transition head + cross-K/V prefill + decode steps" if a.encoder_dtype == "fp32"
+                                 else "encoder (bf16) + transition head + cross-K/V prefill + decode steps")
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vitomr, lens, a.cpu_steps)
         else:
