@@ -19,7 +19,7 @@ from torch.amp import autocast
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from acai_omr.models.models import (MAE, FineTuneOMREncoder, MAELoss, OMRCELoss, OMRDecoder, OMREncoder,  # noqa: E402
+from acai_omr.models.models import (MAE, FineTuneOMREncoder, GRPOViTOMR, MAELoss, OMRCELoss, OMRDecoder, OMREncoder,  # noqa: E402
                                     Encoder, TeacherForcedViTOMR, batchify_and_split_lmx_seqs)
 from oracle import vitomr_oracle as O  # noqa: E402
 
@@ -244,6 +244,103 @@ def gen_encoder_variants(name, seed):
     torch.save(dict(state_dict=sd, imgs=imgs, latent=lat, mask=mask, too_large_msg=msg), os.path.join(OUT, name + ".pt"))
 
 
+def gen_grpo(name, cfg, seed, lat_lens, group, top_k, temperature, max_actions):
+    """GRPOViTOMR.cached_forward_rollout_policy (M:988-1049) under torch.manual_seed, fp32 and autocast(bf16): rollouts, log-probs, mask and
+    the per-step logits.  torch.multinomial's stream cannot be reproduced elsewhere; what IS pinned: for the tokens the reference drew, the
+    logits, the log-probs (log_softmax over the kept logits, M:1017-1018) and the mask.  `uniforms` are the inverse-CDF arguments that make
+    the oracle's (and the HIP kernel's) draw land on the reference's token at every live step."""
+    torch.manual_seed(seed)
+    tf = build_vitomr(cfg)
+    with torch.no_grad():
+        for n, p in tf.named_parameters():
+            if "norm" in n:
+                p.add_(0.1 * torch.randn_like(p))
+            elif n.endswith("bias"):
+                p.add_(0.05 * torch.randn_like(p))
+        tf.decoder.unembed.weight.mul_(4.0)
+        tf.decoder.unembed.bias[2] += 5.0      # some rollouts reach <eos> early: exercises the ragged mask / clipping
+    sd = sd_cpu(tf)
+    E, B, S = cfg["dec_dim"], len(lat_lens), max(lat_lens)
+    g = torch.Generator().manual_seed(seed + 1)
+    mem = torch.randn(B, S, E, generator=g)                    # decoder-side memory (what the GRPO loop hands the policy)
+    mask = torch.arange(S).unsqueeze(0) >= torch.tensor(lat_lens).unsqueeze(1)
+    fx = dict(cfg=cfg, state_dict=sd, mem=mem, mask=mask, lat_lens=lat_lens, group=group, top_k=top_k, temperature=temperature,
+              max_actions=max_actions)
+    for tag, use_ac, cdt in (("fp32", False, torch.float), ("bf16", True, torch.bfloat16)):
+        cached = tf.decoder.to_cached_version(B * group, cdt)
+        cached.load_state_dict(tf.decoder.state_dict())
+        grpo = GRPOViTOMR(tf.encoder, tf.transition_head, cached, sd).eval()
+        mem_x, mask_x = grpo.expand_img_latent_for_rollout(mem, mask, group)
+        rec = []
+        orig = cached.cached_generate
+
+        def wrapped(token_t, time_step, latent_attention_mask=None):
+            out = orig(token_t, time_step, latent_attention_mask)
+            rec.append(out.detach().float().squeeze(1).clone())
+            return out
+
+        cached.cached_generate = wrapped
+        torch.manual_seed(seed + 2)
+        with torch.no_grad():
+            if use_ac:
+                with autocast(device_type="cpu", dtype=torch.bfloat16):
+                    ro, lp, mk = grpo.cached_forward_rollout_policy(mem_x, mask_x, max_actions=max_actions, top_k=top_k, temperature=temperature)
+            else:
+                ro, lp, mk = grpo.cached_forward_rollout_policy(mem_x, mask_x, max_actions=max_actions, top_k=top_k, temperature=temperature)
+        logits = torch.stack(rec, 1)                               # (R, steps, V)
+        R, T = ro.shape
+        # uniforms that reproduce the reference's draws through the inverse-CDF restatement (dead positions: 0.5)
+        u = torch.full((R, max_actions), 0.5)
+        for t in range(1, T):
+            ut, kept = O.rollout_uniform_for_token(logits[:, t - 1], ro[:, t].clamp(min=0), top_k, temperature)
+            live = mk[:, t]
+            assert bool(kept[live].all())
+            u[live, t] = ut[live]
+            tok, olp = O.rollout_sample_step(logits[:, t - 1], u[:, t], top_k, temperature, round_lp=use_ac)
+            assert torch.equal(tok[live], ro[live, t]), (tag, t)
+            # same logits -> same log-prob; under autocast aten's bf16 log_softmax kernel is not "fp32, rounded once": allow 2 bf16 ulps
+            if use_ac:
+                ulp = torch.exp2(torch.floor(torch.log2(lp[live, t].abs().clamp(min=2.0 ** -126))) - 7)
+                assert bool(((olp[live] - lp[live, t]).abs() <= 2 * ulp).all()), (tag, t)
+            else:
+                assert maxdiff(olp[live], lp[live, t]) < 1e-5, (tag, t)
+        fx[tag] = dict(rollouts=ro, log_probs=lp, mask=mk, step_logits=logits, uniforms=u)
+        # the whole loop through the oracle (its own logits): fp32 must land on the reference's rollouts
+        lens_x = [l for l in lat_lens for _ in range(group)]
+        packed = torch.cat([mem[b, :l] for b, l in enumerate(lat_lens) for _ in range(group)], 0)
+        prec = "bf16" if use_ac else "fp32"
+        oro, olps, omk, ologits = O.rollout_generate(packed, lens_x, sd, cfg["dec_heads"], prec, max_actions, top_k, temperature, u, return_logits=True)
+        # rows past their <eos> keep drawing junk that the returned rollouts no longer hold: logits are comparable on live positions only
+        n = min(ologits.shape[1], logits.shape[1], T - 1)
+        live_l = mk[:, 1:n + 1]
+        dl = maxdiff(ologits[:, :n][live_l], logits[:, :n][live_l]) if torch.equal(oro, ro) else float("nan")
+        print(f"[{name}] {tag}: rollouts {tuple(ro.shape)} lens {mk.sum(-1).tolist()}  oracle loop tokens equal = {torch.equal(oro, ro)}  logits max|d| = {dl:.3e}")
+        if not use_ac:
+            assert torch.equal(oro, ro) and torch.equal(omk, mk) and maxdiff(olps, lp) < 1e-4 and dl < 1e-4
+        fx[f"oracle_{tag}_tokens_equal"] = bool(torch.equal(oro, ro))
+    torch.save(fx, os.path.join(OUT, name + ".pt"))
+
+
+def gen_ce_label_smoothing(name, seed):
+    """OMRCELoss(pad_idx, label_smoothing) (M:784-796): loss and d loss / d logits for eps in {0, 0.1}."""
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(4, 7, 227, generator=g) * 2.0
+    target = torch.randint(0, 227, (4, 7), generator=g)
+    target[0, 4:] = 1
+    target[2, 1:] = 1
+    fx = dict(logits=logits, target=target, pad_idx=1)
+    for eps in (0.0, 0.1):
+        lg = logits.clone().requires_grad_(True)
+        loss = OMRCELoss(1, label_smoothing=eps)(lg, target)
+        loss.backward()
+        ol = O.ce_loss(logits, target, 1, label_smoothing=eps)
+        assert abs(float(ol) - float(loss)) < 1e-6, (eps, float(ol), float(loss))
+        fx[f"loss_{eps}"] = loss.detach()
+        fx[f"grad_{eps}"] = lg.grad.detach().clone()
+    print(f"[{name}] label smoothing: loss(0) = {float(fx['loss_0.0']):.6f} loss(0.1) = {float(fx['loss_0.1']):.6f}")
+    torch.save(fx, os.path.join(OUT, name + ".pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     g = torch.Generator().manual_seed(1234)
@@ -278,6 +375,18 @@ def main():
     gen_mae("mae_debug_ckpt", dbg_cfg, dimgs, dimgs, seed=51, sd_override=dbg)
 
     gen_encoder_variants("omr_encoder_interp", seed=61)
+
+    # ---- round 2 additions (own generators: the fixtures above stay bit-identical) ----------------------------------------
+    # GRPO rollout policy (M:988-1049): 2 memories x 3 rollouts on the small decoder (d_h = 12), 2 x 4 at d_h = 64
+    gen_grpo("grpo_small", small, seed=71, lat_lens=[9, 5], group=3, top_k=5, temperature=1.2, max_actions=10)
+    gen_grpo("grpo_dh64", dh64, seed=72, lat_lens=[24, 40], group=4, top_k=8, temperature=0.9, max_actions=9)
+    # teacher-forced TRAIN step whose images exceed the PE grid: batchify interpolates in every mode (M:304-332) and the
+    # gradient reaches pos_embedding through the bilinear interpolation (full fine-tune: pos_embedding trainable, M:667-677)
+    g2 = torch.Generator().manual_seed(4321)
+    interp = dict(small, ft_depth=2, lmx_lens=[5, 9, 3])
+    imgs_interp = [torch.rand(1, 8, 16, generator=g2), torch.rand(1, 28, 44, generator=g2), torch.rand(1, 12, 48, generator=g2)]
+    gen_teacher_forced("tf_interp", interp, imgs_interp, seed=81)
+    gen_ce_label_smoothing("ce_label_smoothing", seed=91)
     print("golden vectors written to", OUT)
 
 

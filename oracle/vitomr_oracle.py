@@ -439,9 +439,16 @@ def teacher_forced_forward(batch, sd, enc_heads, dec_heads, P, prec, enc_kind="o
     return pred.reshape(B, T, -1), tgt
 
 
-def ce_loss(pred, target, pad_idx=1):
-    """OMRCELoss (M:784-796): mean over non-pad targets."""
-    return F.cross_entropy(pred.reshape(-1, pred.shape[-1]).float(), target.reshape(-1), ignore_index=pad_idx)
+def ce_loss(pred, target, pad_idx=1, label_smoothing=0.0):
+    """OMRCELoss (M:784-796): mean over non-pad targets of (1 - eps) * nll + eps / V * sum_c(-log p_c) (nn.CrossEntropyLoss with
+    ignore_index and label_smoothing = eps, restated; eps = 0 is the plain NLL)."""
+    lp = torch.log_softmax(pred.reshape(-1, pred.shape[-1]).float(), dim=-1)
+    tg = target.reshape(-1)
+    keep = tg != pad_idx
+    nll = -lp.gather(-1, tg.clamp(min=0).unsqueeze(1)).squeeze(1)
+    smooth = -lp.mean(dim=-1)
+    per = (1.0 - label_smoothing) * nll + label_smoothing * smooth
+    return (per * keep).sum() / keep.sum()
 
 
 # ----------------------------------------------------------------------------
@@ -522,3 +529,48 @@ def rollout_sample_step(logits, u, top_k, temperature, round_lp=False):
     if round_lp:
         lp = lp.to(torch.bfloat16).float()
     return tok, lp
+
+
+def rollout_uniform_for_token(logits, tok, top_k, temperature):
+    """The uniform u for which `rollout_sample_step(logits, u, ...)` draws `tok` (R,): the midpoint of tok's interval of the tempered CDF
+    over the kept logits in descending order (ties: lower index first).  Lets a rollout the REFERENCE drew with torch.multinomial
+    (M:1008) be replayed through the inverse-CDF draw of this restatement and of the HIP kernel.  Also returns whether tok was kept."""
+    logits = logits.float()
+    vals, idx = torch.sort(logits, dim=-1, descending=True, stable=True)
+    vals, idx = vals[:, :top_k], idx[:, :top_k]
+    pT = torch.exp((vals - vals[:, :1]) / temperature)
+    cdf = torch.cumsum(pT, dim=-1)
+    hit = idx == tok.unsqueeze(1)
+    kept = hit.any(-1)
+    r = hit.float().argmax(-1)
+    hi = cdf.gather(-1, r.unsqueeze(1)).squeeze(1)
+    lo = hi - pT.gather(-1, r.unsqueeze(1)).squeeze(1)
+    return (0.5 * (lo + hi) / pT.sum(-1)).clamp(0.0, 1.0 - 1e-7), kept
+
+
+def rollout_generate(mem, lens_s, sd, num_heads, prec, max_actions, top_k, temperature, uniforms, bos_idx=0, pad_idx=1, eos_idx=2,
+                     prefix="decoder.", return_logits=False):
+    """GRPOViTOMR.cached_forward_rollout_policy (M:988-1049) with the draw of every step taken from `uniforms` (R, max_actions): the greedy
+    loop's plumbing (quirk Q1 included, M:1000) with `rollout_sample_step` in place of the arg-max; rows after their first <eos> are
+    padded / zeroed and the result is clipped to the longest rollout (M:1036-1047)."""
+    R = len(lens_s)
+    state = DecodeState(mem, lens_s, sd, num_heads, prec, prefix)
+    ro = torch.full((R, max_actions), pad_idx, dtype=torch.long)
+    ro[:, 0] = bos_idx
+    lps = torch.zeros(R, max_actions)
+    finished = torch.zeros(R, dtype=torch.bool)
+    all_logits = []
+    for t in range(1, max_actions):
+        logits = decode_step(state, ro[:, t - 1], t)
+        if return_logits:
+            all_logits.append(logits)
+        tok, lp = rollout_sample_step(logits, uniforms[:, t], top_k, temperature, round_lp=(prec == "bf16"))
+        ro[:, t] = tok
+        lps[:, t] = lp
+        finished |= tok == eos_idx
+        if bool(finished.all()):
+            break
+    out = mask_and_clip(ro, lps, eos_idx, pad_idx)
+    if return_logits:
+        return out + (torch.stack(all_logits, 1),)
+    return out

@@ -43,8 +43,10 @@ def test_decode_bf16_autocast_plumbing(name):
     assert md(lps, ref["log_probs"]) < 0.13  # bf16 log-probs: one or two ulps at |x| ~ 4-8
 
 
-@pytest.mark.parametrize("name", ["tf_small", "tf_dh64"])
+@pytest.mark.parametrize("name", ["tf_small", "tf_dh64", "tf_interp"])
 def test_teacher_forced_loss_and_grads(name):
+    """tf_interp: two of the three images exceed the PE grid, so batchify interpolates IN THE TRAINING PATH (models.py:304-332) and the
+    gradient of pos_embedding flows through the bilinear interpolation."""
     fx = load_golden(name)
     cfg = fx["cfg"]
     sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in fx["state_dict"].items()}
@@ -87,6 +89,47 @@ def test_omr_encoder_pe_interpolation_and_too_large_error():
     with pytest.raises(ValueError) as e:
         O.encoder_forward([torch.rand(1, 28, 44)], sd, "", 4, 2, "base")
     assert str(e.value) == fx["too_large_msg"]
+
+
+@pytest.mark.parametrize("name", ["grpo_small", "grpo_dh64"])
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+def test_grpo_rollout_policy_vs_reference(name, tag):
+    """GRPOViTOMR.cached_forward_rollout_policy (models.py:988-1049) as the imported reference ran it under torch.manual_seed: with the
+    fixture's uniforms (the inverse-CDF arguments of the reference's own draws) the oracle's sampling step reproduces every live token and
+    its log-prob from the REFERENCE's per-step logits, and the oracle's whole rollout loop (its own logits) lands on the same rollouts."""
+    fx = load_golden(name)
+    cfg, ref = fx["cfg"], fx[tag]
+    ro, lp, mk, logits, u = ref["rollouts"], ref["log_probs"], ref["mask"], ref["step_logits"], ref["uniforms"]
+    bf = tag == "bf16"
+    assert torch.equal(mk, O.inference_mask(ro, 2)) and bool((ro[~mk] == 1).all()) and bool((lp[~mk] == 0).all())
+    assert mk.sum(-1).min() < ro.shape[1]            # ragged: some rollouts ended early
+    for t in range(1, ro.shape[1]):
+        tok, olp = O.rollout_sample_step(logits[:, t - 1], u[:, t], fx["top_k"], fx["temperature"], round_lp=bf)
+        live = mk[:, t]
+        assert torch.equal(tok[live], ro[live, t])
+        if bf:   # aten's bf16 log_softmax kernel is not "fp32, rounded once": two bf16 ulps
+            ulp = torch.exp2(torch.floor(torch.log2(lp[live, t].abs().clamp(min=2.0 ** -126))) - 7)
+            assert bool(((olp[live] - lp[live, t]).abs() <= 2 * ulp).all())
+        else:
+            assert md(olp[live], lp[live, t]) < 1e-5
+    G, lens = fx["group"], fx["lat_lens"]
+    lens_x = [l for l in lens for _ in range(G)]
+    packed = torch.cat([fx["mem"][b, :l] for b, l in enumerate(lens) for _ in range(G)], 0)
+    oro, olps, omk = O.rollout_generate(packed, lens_x, fx["state_dict"], cfg["dec_heads"], tag, fx["max_actions"], fx["top_k"], fx["temperature"], u)
+    assert fx[f"oracle_{tag}_tokens_equal"]
+    assert torch.equal(oro, ro) and torch.equal(omk, mk)
+    assert md(olps, lp) < (0.07 if bf else 1e-4)
+
+
+def test_ce_loss_label_smoothing_vs_reference():
+    """OMRCELoss(pad_idx, label_smoothing) (models.py:784-796) for eps = 0 and 0.1: value and gradient."""
+    fx = load_golden("ce_label_smoothing")
+    for eps in (0.0, 0.1):
+        lg = fx["logits"].clone().requires_grad_(True)
+        loss = O.ce_loss(lg, fx["target"], fx["pad_idx"], label_smoothing=eps)
+        assert abs(float(loss) - float(fx[f"loss_{eps}"])) < 1e-6
+        loss.backward()
+        assert md(lg.grad, fx[f"grad_{eps}"]) < 1e-7
 
 
 # ---- the reference's own known-answer tests, restated on the oracle ----------------------------
