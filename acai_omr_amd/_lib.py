@@ -25,11 +25,12 @@ class AcaiDecLayer(Structure):
 
 
 class AcaiAdamWTensor(Structure):
-    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64), ("group", c_int32), ("pad_", c_int32)]
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64), ("group", c_int32), ("pad_", c_int32),
+                ("bias_c1", c_float), ("bias_c2_sqrt", c_float)]
 
 
 class AcaiAdamWGroup(Structure):
-    _fields_ = [(n, c_float) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "bias_c1", "bias_c2_sqrt", "pad_")]
+    _fields_ = [(n, c_float) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "pad0_", "pad1_", "pad2_")]
 
 
 class AcaiDecoder(Structure):
@@ -69,7 +70,9 @@ _SIGNATURES = {
     "acai_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "acai_scatter_add_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "acai_mae_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "acai_ce_loss": (c_int, [c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "acai_ce_loss": (c_int, [c_void_p, c_int, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "acai_pe_interp_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "acai_pe_interp_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "acai_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "acai_skinny_gemm": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_void_p]),
@@ -91,16 +94,38 @@ _lib = None
 
 
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -shared over csrc/*.hip -> csrc/libacai_omr_hip.so (in-tree)."""
+    """hipcc --offload-arch=gfx950 over csrc/*.hip -> csrc/libacai_omr_hip.so (in-tree).  One object per source (rebuilt only when the
+    source or a shared header is newer), compiled in parallel, then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(CSRC), "..", "include", "acai_omr_hip.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(CSRC), "..", "include", "acai_omr_hip.h")]
     hipcc = "hipcc" if subprocess.run(["which", "hipcc"], capture_output=True).returncode == 0 else "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", LIB_PATH] + srcs
+    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+
+    def stale(out, deps):
+        return force or not os.path.exists(out) or any(os.path.getmtime(out) < os.path.getmtime(d) for d in deps)
+
+    jobs = []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if stale(obj, [src] + hdrs):
+            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+        for j in jobs:
+            print(" ".join(j))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as ex:
+            for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
+                if r.returncode != 0:
+                    raise RuntimeError(f"hipcc failed: {' '.join(r.args)}\n{r.stdout}\n{r.stderr}")
+    objs = [os.path.join(objdir, os.path.basename(src) + ".o") for src in srcs]
+    if jobs or stale(LIB_PATH, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
     return LIB_PATH
 
 

@@ -124,6 +124,45 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restric
     }
 }
 
+// OMREncoder.interpolate_pe (M:291-302) = aten upsample_bilinear2d, align_corners = False, on the (Hin, Win, E) table; one wave per output
+// grid cell, lanes over E.  BWD = the transposed stencil (four float atomics per element: the table is tiny and L2-resident).
+struct Bilin { int y0, y1, x0, x1; float ly, lx; };
+__device__ __forceinline__ Bilin bilin_of(int oy, int ox, int Hin, int Win, float sh, float sw) {
+    Bilin b;
+    const float fy = fmaxf(sh * ((float)oy + 0.5f) - 0.5f, 0.f), fx = fmaxf(sw * ((float)ox + 0.5f) - 0.5f, 0.f);
+    b.y0 = min((int)fy, Hin - 1);
+    b.x0 = min((int)fx, Win - 1);
+    b.y1 = b.y0 + (b.y0 < Hin - 1 ? 1 : 0);
+    b.x1 = b.x0 + (b.x0 < Win - 1 ? 1 : 0);
+    b.ly = fy - (float)b.y0;
+    b.lx = fx - (float)b.x0;
+    return b;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void pe_interp_kernel(const float *__restrict__ src, float *dst, int Hin, int Win, int E, int Hout, int Wout,
+                                                        float sh, float sw) {
+    const int lane = threadIdx.x & 63, cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cell >= Hout * Wout) return;
+    const int oy = cell / Wout, ox = cell - oy * Wout;
+    const Bilin b = bilin_of(oy, ox, Hin, Win, sh, sw);
+    const float hy = 1.f - b.ly, hx = 1.f - b.lx;
+    const size_t r00 = ((size_t)b.y0 * Win + b.x0) * E, r01 = ((size_t)b.y0 * Win + b.x1) * E, r10 = ((size_t)b.y1 * Win + b.x0) * E,
+                 r11 = ((size_t)b.y1 * Win + b.x1) * E, ro = (size_t)cell * E;
+    for (int e = lane; e < E; e += 64) {
+        if constexpr (!BWD) {
+            // aten: h0lambda * (w0lambda * v00 + w1lambda * v01) + h1lambda * (w0lambda * v10 + w1lambda * v11)
+            dst[ro + e] = hy * (hx * src[r00 + e] + b.lx * src[r01 + e]) + b.ly * (hx * src[r10 + e] + b.lx * src[r11 + e]);
+        } else {
+            const float g = src[ro + e];
+            atomicAdd(dst + r00 + e, hy * hx * g);
+            atomicAdd(dst + r01 + e, hy * b.lx * g);
+            atomicAdd(dst + r10 + e, b.ly * hx * g);
+            atomicAdd(dst + r11 + e, b.ly * b.lx * g);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float *__restrict__ x, bf16_t *y, long n) {
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     const long stride = (long)gridDim.x * 1024;
@@ -191,6 +230,22 @@ extern "C" int acai_gather_rows(const float *table, const int32_t *idx, const fl
     else
         hipLaunchKernelGGL(gather_rows_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, st, table, idx, add, out, rows, dim);
     ACAI_LAUNCH_CHECK("acai_gather_rows");
+    return 0;
+}
+
+extern "C" int acai_pe_interp_fwd(const float *table, int Hin, int Win, int E, float *out, int Hout, int Wout, void *stream) {
+    ACAI_CHECK_ARG(table && out && Hin > 0 && Win > 0 && E > 0 && Hout > 0 && Wout > 0, "acai_pe_interp_fwd: bad arguments");
+    hipLaunchKernelGGL(pe_interp_kernel<false>, dim3(cdiv(Hout * Wout, 4)), dim3(256), 0, (hipStream_t)stream, table, out, Hin, Win, E, Hout, Wout,
+                       (float)Hin / (float)Hout, (float)Win / (float)Wout);
+    ACAI_LAUNCH_CHECK("acai_pe_interp_fwd");
+    return 0;
+}
+
+extern "C" int acai_pe_interp_bwd(const float *dout, int Hout, int Wout, int E, float *dtable, int Hin, int Win, void *stream) {
+    ACAI_CHECK_ARG(dout && dtable && Hin > 0 && Win > 0 && E > 0 && Hout > 0 && Wout > 0, "acai_pe_interp_bwd: bad arguments");
+    hipLaunchKernelGGL(pe_interp_kernel<true>, dim3(cdiv(Hout * Wout, 4)), dim3(256), 0, (hipStream_t)stream, dout, dtable, Hin, Win, E, Hout, Wout,
+                       (float)Hin / (float)Hout, (float)Win / (float)Wout);
+    ACAI_LAUNCH_CHECK("acai_pe_interp_bwd");
     return 0;
 }
 

@@ -295,8 +295,9 @@ __global__ __launch_bounds__(256) void mae_loss_kernel(const float *__restrict__
 }
 
 // ---- OMRCELoss fwd + bwd: rows with target == ignore contribute nothing; mean over the others ------------------------------
+// label smoothing eps (nn.CrossEntropyLoss: row loss = (1 - eps) * nll + eps / V * sum_c -log p_c; d/dlogit_c = p_c - (1 - eps) [c == t] - eps / V)
 __global__ __launch_bounds__(256) void ce_loss_kernel(const float *__restrict__ logits, int ld, const int64_t *__restrict__ target, int ignore,
-                                                      float inv_count, float *loss, float *dlogits, int rows, int V) {
+                                                      float inv_count, float *loss, float *dlogits, int rows, int V, float eps) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float *lg = logits + (size_t)row * ld;
@@ -309,13 +310,22 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float *__restrict__ 
     float m = -INFINITY;
     for (int i = lane; i < V; i += 64) m = fmaxf(m, lg[i]);
     m = wave_max(m);
-    float se = 0.f;
-    for (int i = lane; i < V; i += 64) se += expf(lg[i] - m);
+    float se = 0.f, sl = 0.f;
+    for (int i = lane; i < V; i += 64) {
+        se += expf(lg[i] - m);
+        sl += lg[i];
+    }
     se = wave_sum(se);
     const float lse = m + logf(se);
+    const float uni = eps / (float)V;
     if (dlogits)
-        for (int i = lane; i < V; i += 64) dlogits[(size_t)row * V + i] = (expf(lg[i] - lse) - (i == tg ? 1.f : 0.f)) * inv_count;
-    if (lane == 0) atomicAdd(loss, (lse - lg[tg]) * inv_count);
+        for (int i = lane; i < V; i += 64) dlogits[(size_t)row * V + i] = (expf(lg[i] - lse) - (i == tg ? 1.f - eps : 0.f) - uni) * inv_count;
+    if (eps != 0.f) sl = wave_sum(sl);
+    if (lane == 0) {
+        float v = (1.f - eps) * (lse - lg[tg]);
+        if (eps != 0.f) v += eps * (lse - sl / (float)V);
+        atomicAdd(loss, v * inv_count);
+    }
 }
 
 // out = residual + keep(row, col) * x / (1 - p)   (nn.Dropout after a projection, then the residual add; also its own backward:
@@ -429,11 +439,12 @@ extern "C" int acai_mae_loss(const float *pred, const float *target, const unsig
     return 0;
 }
 
-extern "C" int acai_ce_loss(const float *logits, int ld, const int64_t *target, int ignore_index, float inv_count, float *loss, float *dlogits,
-                            int rows, int V, void *stream) {
-    ACAI_CHECK_ARG(logits && target && loss && rows >= 0 && V > 0 && ld >= V, "acai_ce_loss: bad arguments");
+extern "C" int acai_ce_loss(const float *logits, int ld, const int64_t *target, int ignore_index, float inv_count, float label_smoothing, float *loss,
+                            float *dlogits, int rows, int V, void *stream) {
+    ACAI_CHECK_ARG(logits && target && loss && rows >= 0 && V > 0 && ld >= V && label_smoothing >= 0.f && label_smoothing <= 1.f, "acai_ce_loss: bad arguments");
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(ce_loss_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits, ld, target, ignore_index, inv_count, loss, dlogits, rows, V);
+    hipLaunchKernelGGL(ce_loss_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits, ld, target, ignore_index, inv_count, loss, dlogits, rows, V,
+                       label_smoothing);
     ACAI_LAUNCH_CHECK("acai_ce_loss");
     return 0;
 }
@@ -473,13 +484,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AcaiAdamWTensor *__res
     const int64_t n = min((int64_t)chunk_elems, t.n - off);
     float *p = t.p + off, *m = t.m + off, *v = t.v + off;
     const float *g = t.g + off;
-    const float decay = 1.0f - h.lr * h.weight_decay, step_size = h.lr / h.bias_c1, omb1 = 1.0f - h.beta1, omb2 = 1.0f - h.beta2;
+    const float decay = 1.0f - h.lr * h.weight_decay, step_size = h.lr / t.bias_c1, omb1 = 1.0f - h.beta1, omb2 = 1.0f - h.beta2;
     auto upd = [&](float &pp, float gg, float &mm, float &vv) {
         gg *= grad_scale;
         pp *= decay;
         mm += (gg - mm) * omb1;
         vv = vv * h.beta2 + omb2 * gg * gg;
-        pp -= step_size * (mm / (sqrtf(vv) / h.bias_c2_sqrt + h.eps));
+        pp -= step_size * (mm / (sqrtf(vv) / t.bias_c2_sqrt + h.eps));
     };
     if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
         const int64_t n4 = n >> 2;

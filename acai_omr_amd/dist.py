@@ -38,6 +38,16 @@ def global_mean_scale(local_count, group=None, device=None):
 
 
 class GradAllReduce:
+    """Bucketed gradient SUM all-reduce.  Usage per optimizer step:
+
+        ddp.zero_grad()                     # in place: the buckets stay attached (optimizer.zero_grad() also works, see _hook)
+        with ddp.no_sync(): ...backward()   # optional earlier micro-batches: gradients accumulate locally
+        loss.backward()                     # hooks launch one asynchronous all-reduce per completed bucket
+        ddp.finish()                        # waits; reduces buckets the hooks did not complete
+        optimizer.step()
+
+    A second synchronising backward before finish() would reduce a bucket twice - that is refused, loudly."""
+
     def __init__(self, module, bucket_mb=25.0, group=None):
         self.group = group
         self.params = [p for p in module.parameters() if p.requires_grad]
@@ -45,6 +55,7 @@ class GradAllReduce:
         self._handles = []
         cap = int(bucket_mb * 1024 * 1024 // 4)
         self.buckets = []  # (flat tensor, [params])
+        self._view = {}    # id(p) -> its slice of the bucket
         cur, n = [], 0
         for p in reversed(self.params):
             if cur and n + p.numel() > cap:
@@ -55,6 +66,7 @@ class GradAllReduce:
         if cur:
             self._make_bucket(cur)
         self._pending = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
         self._bucket_of = {}
         for bi, (_, ps) in enumerate(self.buckets):
             for p in ps:
@@ -65,14 +77,21 @@ class GradAllReduce:
         flat = torch.zeros(sum(p.numel() for p in ps), dtype=torch.float32, device=ps[0].device)
         o = 0
         for p in ps:
-            p.grad = flat[o:o + p.numel()].view_as(p)   # autograd accumulates in place into the bucket
+            v = flat[o:o + p.numel()].view_as(p)
+            self._view[id(p)] = v
+            p.grad = v   # autograd accumulates in place into the bucket
             o += p.numel()
         self.buckets.append((flat, ps))
 
     def zero_grad(self):
-        for flat, _ in self.buckets:
+        """Zero the buckets in place and (re-)attach every .grad to its slice."""
+        for flat, ps in self.buckets:
             flat.zero_()
+            for p in ps:
+                if p.grad is not self._view[id(p)]:
+                    p.grad = self._view[id(p)]
         self._pending = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -82,25 +101,47 @@ class GradAllReduce:
         finally:
             self._sync = old
 
+    def _attach(self, p):
+        """`optimizer.zero_grad()` defaults to set_to_none=True, which drops the bucket views; the next backward then allocates a fresh
+        .grad.  Move it into the bucket slice (whose old content belongs to a previous step) and re-attach, so the all-reduce sees it."""
+        v = self._view[id(p)]
+        g = p.grad
+        if g is not None and g.data_ptr() != v.data_ptr():
+            v.copy_(g)
+            p.grad = v
+
     def _hook(self, p):
+        self._attach(p)
         if not self._sync:
             return
         bi = self._bucket_of[id(p)]
+        if self._launched[bi]:
+            raise RuntimeError("GradAllReduce: a bucket that was already all-reduced received more gradient before finish(); wrap the earlier "
+                               "micro-batches of an accumulation in no_sync() and call finish() before optimizer.step()")
         self._pending[bi] += 1
         if self._pending[bi] == len(self.buckets[bi][1]):
             self._launch(bi)
 
     def _launch(self, bi):
+        self._launched[bi] = True
         if dist.is_initialized() and dist.get_world_size(self.group) > 1:
             self._handles.append(dist.all_reduce(self.buckets[bi][0], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
-        """Wait for the outstanding all-reduces; parameters that received no gradient this step still have to be reduced."""
-        if self._sync:
-            for bi, n in enumerate(self._pending):
-                if n != len(self.buckets[bi][1]):   # bucket not launched by the hooks (some parameter got no gradient)
-                    self._launch(bi)
+        """Wait for the outstanding all-reduces; buckets the hooks did not complete (a parameter without gradient this step, or the last
+        backward ran under no_sync) are reduced here.  A parameter whose .grad is None keeps None: its slice is zeroed first so that stale
+        content of an earlier step is not summed into the other ranks' gradients."""
+        for bi, (flat, ps) in enumerate(self.buckets):
+            if self._launched[bi]:
+                continue
+            for p in ps:
+                if p.grad is None:
+                    self._view[id(p)].zero_()
+                else:
+                    self._attach(p)
+            self._launch(bi)
         for h in self._handles:
             h.wait()
         self._handles = []
         self._pending = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)

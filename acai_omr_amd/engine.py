@@ -25,6 +25,18 @@ class WeightCache:
     def __init__(self):
         self._c = {}
 
+    # derived data keyed on parameter identity: a copied / pickled module starts with an empty cache
+    def __deepcopy__(self, memo):
+        return WeightCache()
+
+    def __reduce__(self):
+        return (WeightCache, ())
+
+    def invalidate(self):
+        """Drop every cached copy.  Needed after writes that do not move a parameter's version counter (`p.data.copy_`, EMA through `.data`,
+        weight surgery): the cache keys on (version, storage pointer).  `load_state_dict` and optimizer steps bump versions and need no call."""
+        self._c.clear()
+
     def _get(self, p, kind, make):
         key = (id(p), kind)
         tag = (p._version, p.data_ptr())

@@ -202,6 +202,15 @@ class CachedTransformerDecoder(nn.TransformerDecoder):
         self.__dict__["_pending"] = None
         self.__dict__["_omr"] = None  # set by OMRDecoder so that the fused step can embed / unembed
 
+    def __getstate__(self):
+        """copy.deepcopy(model) / torch.save(model) (the reference's GRPO loop deep-copies its policy, omr_grpo_train.py): the decode engine
+        (ctypes descriptors with raw pointers, a stream, captured graphs) is per-instance runtime state and is rebuilt on first use."""
+        st = self.__dict__.copy()
+        st["_engine"] = None
+        st["_pending"] = None
+        st.pop("_mask_lens", None)
+        return st
+
     def engine(self, device):
         eng = self.__dict__["_engine"]
         if eng is None or eng.device != torch.device(device):

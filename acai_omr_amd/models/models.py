@@ -246,9 +246,10 @@ class OMREncoder(Encoder):
     _allow_pe_interpolation = True
 
     def interpolate_pe(self, h_p, w_p):
-        g = self.pos_embedding.permute(2, 0, 1).unsqueeze(0)
-        g = nn.functional.interpolate(g, size=(h_p, w_p), mode="bilinear", align_corners=False)
-        return g.squeeze(0).permute(1, 2, 0)
+        """(h_p, w_p, E) bilinear resampling of the PE grid, align_corners=False (M:291-302), by the HIP kernel; differentiable w.r.t.
+        pos_embedding when it requires grad (the reference interpolates in batchify in every mode, M:315-318)."""
+        from ..train import autograd_path
+        return autograd_path.PeInterpFn.apply(self.pos_embedding, h_p, w_p).view(h_p, w_p, self.hidden_dim)
 
 
 class FineTuneOMREncoder(OMREncoder):
@@ -497,11 +498,13 @@ class ViTOMR(nn.Module):
         blocks.prepare_caches_packed(mem32, None, lens)
         eng = blocks.engine(self.decoder.pos_embedding.device)
         # replay the decode graph flush_interval tokens at a time; after each chunk hand out the freshly written tokens
+        # (the reference yields STEP at every t % flush_interval == 0 that did not finish the sequence - also at t == max_len - 1, M:641-645)
         for t_done, finished in eng.greedy_chunks(max_len, flush_interval):
-            if finished or t_done >= max_len - 1:
+            if finished:
                 break
-            buf = eng.seqs[:1, t_done - flush_interval + 1:t_done + 1].to(torch.int)
-            yield {"type": InferenceEvent.STEP.value, "payload": {"tokens": buf}}
+            if t_done % flush_interval == 0:
+                buf = eng.seqs[:1, t_done - flush_interval + 1:t_done + 1].to(torch.int)
+                yield {"type": InferenceEvent.STEP.value, "payload": {"tokens": buf}}
         seqs, lps, mask = self.mask_and_clip_seqs(eng.seqs[:1, :max_len].clone(), eng.logprobs[:1, :max_len].clone())
         yield {"type": InferenceEvent.INFERENCE_FINISH.value, "payload": {"sequence": seqs, "log_probs": lps, "mask": mask}}
 
@@ -675,12 +678,10 @@ class OMRCELoss(nn.Module):
         super().__init__()
         self.pad_idx = pad_idx
         self.label_smoothing = label_smoothing
-        if label_smoothing != 0.0:
-            raise NotImplementedError("label_smoothing != 0 is not used by the reference configs (LABEL_SMOOTHING = 0.0) and not built")
 
     def forward(self, pred, target_seqs):
         from ..train import autograd_path
-        return autograd_path.ce_loss(pred, target_seqs, self.pad_idx)
+        return autograd_path.ce_loss(pred, target_seqs, self.pad_idx, self.label_smoothing)
 
 
 class ScheduledSamplingViTOMR(TeacherForcedViTOMR):

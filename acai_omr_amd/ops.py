@@ -4,14 +4,38 @@ PyTorch is plumbing here: it owns device memory and the current stream; every FL
 the HIP library.  Every wrapper checks device / dtype / contiguity on the host before the launch (a
 faulting kernel can take the whole node down) and raises RuntimeError on a non-zero return code.
 """
+import functools
+
 import torch
 
 from . import _lib
 from ._lib import ACAI_BF16, ACAI_F32, GEMM_GELU, GEMM_ROUND_BF16  # noqa: F401
 
 
-def _st():
-    return torch.cuda.current_stream().cuda_stream
+def _st(t=None):
+    """Raw handle of torch's current stream on `t`'s device (the current device when t is None).  Every public wrapper below runs under
+    `_on_operand_device`, which makes the operands' device current first, so both forms name the same stream."""
+    return torch.cuda.current_stream(t.device if t is not None else None).cuda_stream
+
+
+def _on_operand_device(fn):
+    """Launch on the OPERANDS' device: a model on cuda:N while another device is current (set_up_omr_inference(device="cuda:1"), a DP rank
+    that never called set_device) would otherwise get device 0's stream against device-N pointers - a memory fault without peer access.
+    Mixed-device operands are refused."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kw):
+        idx = -1
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if idx < 0:
+                    idx = a.device.index
+                elif a.device.index != idx:
+                    raise RuntimeError(f"{fn.__name__}: operands on different GPUs (cuda:{idx} and {a.device})")
+        if idx >= 0 and idx != torch.cuda.current_device():
+            with torch.cuda.device(idx):
+                return fn(*args, **kw)
+        return fn(*args, **kw)
+    return wrapped
 
 
 def _dt(t):
@@ -312,14 +336,40 @@ def mae_loss(pred, target, mask, count, want_grad):
     return loss[0], dpred
 
 
-def ce_loss(logits, target, ignore_index, count, want_grad):
+def pe_interp(table, h_out, w_out):
+    """table (Hin, Win, E) fp32 -> (h_out * w_out, E): bilinear, align_corners=False (OMREncoder.interpolate_pe, models.py:291-302)."""
+    _chk(table, "table", torch.float32)
+    assert table.dim() == 3 and table.is_contiguous()
+    Hin, Win, E = table.shape
+    out = torch.empty(int(h_out) * int(w_out), E, dtype=torch.float32, device=table.device)
+    _lib.check(_lib.lib().acai_pe_interp_fwd(table.data_ptr(), Hin, Win, E, out.data_ptr(), int(h_out), int(w_out), _st(table)), "acai_pe_interp_fwd")
+    return out
+
+
+def pe_interp_bwd(dout, h_out, w_out, table_shape):
+    """Gradient of pe_interp w.r.t. the table: (Hin, Win, E) fp32."""
+    _chk(dout, "dout", torch.float32)
+    Hin, Win, E = table_shape
+    assert dout.is_contiguous() and dout.shape == (int(h_out) * int(w_out), E)
+    dt = torch.zeros(Hin, Win, E, dtype=torch.float32, device=dout.device)
+    _lib.check(_lib.lib().acai_pe_interp_bwd(dout.data_ptr(), int(h_out), int(w_out), E, dt.data_ptr(), Hin, Win, _st(dout)), "acai_pe_interp_bwd")
+    return dt
+
+
+def ce_loss(logits, target, ignore_index, count, want_grad, label_smoothing=0.0):
     _chk(logits, "logits", torch.float32), _chk(target, "target", torch.int64)
     assert logits.dim() == 2 and target.numel() == logits.shape[0] and target.is_contiguous()
     loss = torch.zeros(1, dtype=torch.float32, device=logits.device)
     dl = torch.empty(logits.shape, dtype=torch.float32, device=logits.device) if want_grad else None
-    _lib.check(_lib.lib().acai_ce_loss(logits.data_ptr(), logits.stride(0), target.data_ptr(), int(ignore_index), 1.0 / float(count), loss.data_ptr(),
-                                       _p(dl), logits.shape[0], logits.shape[1], _st()), "acai_ce_loss")
+    _lib.check(_lib.lib().acai_ce_loss(logits.data_ptr(), logits.stride(0), target.data_ptr(), int(ignore_index), 1.0 / float(count), float(label_smoothing),
+                                       loss.data_ptr(), _p(dl), logits.shape[0], logits.shape[1], _st(logits)), "acai_ce_loss")
     return loss[0], dl
+
+
+for _name, _fn in list(globals().items()):
+    if callable(_fn) and not _name.startswith("_") and getattr(_fn, "__module__", None) == __name__ and not isinstance(_fn, type):
+        globals()[_name] = _on_operand_device(_fn)
+del _name, _fn
 
 
 class Graph:

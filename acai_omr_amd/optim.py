@@ -38,7 +38,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("FusedAdamW: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._layout = None  # (key, tensors_dev, chunk_tensor_dev, chunk_off_dev, n_chunks, holders)
+        self._layout = None  # (key, chunk_tensor_dev, chunk_off_dev, n_chunks)
 
     # ---- tables -----------------------------------------------------------------------------------------------------------------------
     def _active(self):
@@ -59,21 +59,26 @@ class FusedAdamW(torch.optim.Optimizer):
                 out.append((gi, p, st))
         return out
 
-    def _build(self, active, dev):
+    def _build(self, active, dev, steps):
+        """Tensor table (pointers + per-tensor bias corrections: torch keeps `step` per parameter, so a parameter that skipped steps - frozen
+        for a while, no gradient - carries its own count) and the chunk table.  The chunk table is rebuilt only when the pointers change; the
+        tensor table is re-uploaded every step (its bias corrections move)."""
         key = tuple((gi, p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()) for gi, p, st in active)
-        if self._layout is not None and self._layout[0] == key:
-            return self._layout
         arr = (_lib.AcaiAdamWTensor * len(active))()
-        ct, co = [], []
         for i, (gi, p, st) in enumerate(active):
             arr[i].p, arr[i].g, arr[i].m, arr[i].v = p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
             arr[i].n, arr[i].group = p.numel(), gi
-            for off in range(0, p.numel(), CHUNK):
-                ct.append(i)
-                co.append(off)
+            b1, b2 = self.param_groups[gi]["betas"]
+            arr[i].bias_c1, arr[i].bias_c2_sqrt = 1.0 - b1 ** steps[i], math.sqrt(1.0 - b2 ** steps[i])
         raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-        self._layout = (key, raw, torch.tensor(ct, dtype=torch.int32).to(dev), torch.tensor(co, dtype=torch.int64).to(dev), len(ct))
-        return self._layout
+        if self._layout is None or self._layout[0] != key:
+            ct, co = [], []
+            for i, (gi, p, st) in enumerate(active):
+                for off in range(0, p.numel(), CHUNK):
+                    ct.append(i)
+                    co.append(off)
+            self._layout = (key, torch.tensor(ct, dtype=torch.int32).to(dev), torch.tensor(co, dtype=torch.int64).to(dev), len(ct))
+        return raw, self._layout[1], self._layout[2], self._layout[3]
 
     # ---- step ---------------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -86,20 +91,17 @@ class FusedAdamW(torch.optim.Optimizer):
         if not active:
             return loss
         dev = active[0][1].device
-        steps = {}
+        steps = []
         for gi, p, st in active:
             st["step"] += 1
-            steps.setdefault(gi, float(st["step"]))
-            if float(st["step"]) != steps[gi]:
-                raise RuntimeError("FusedAdamW: parameters of one group must share their step count")
+            steps.append(float(st["step"]))
         garr = (_lib.AcaiAdamWGroup * len(self.param_groups))()
         for gi, group in enumerate(self.param_groups):
-            t = steps.get(gi, 1.0)
             b1, b2 = group["betas"]
             garr[gi].lr, garr[gi].beta1, garr[gi].beta2, garr[gi].eps = float(group["lr"]), b1, b2, group["eps"]
-            garr[gi].weight_decay, garr[gi].bias_c1, garr[gi].bias_c2_sqrt = group["weight_decay"], 1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t)
+            garr[gi].weight_decay = group["weight_decay"]
         gdev = torch.frombuffer(bytearray(bytes(garr)), dtype=torch.uint8).to(dev)
-        _, tdev, ctd, cod, n_chunks = self._build(active, dev)
+        tdev, ctd, cod, n_chunks = self._build(active, dev, steps)
         with torch.cuda.device(dev):
             st_ = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             _lib.check(_lib.lib().acai_adamw_step(tdev.data_ptr(), gdev.data_ptr(), ctd.data_ptr(), cod.data_ptr(), n_chunks, CHUNK, float(grad_scale), st_),

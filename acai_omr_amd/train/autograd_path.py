@@ -366,6 +366,20 @@ class GatherRowsFn(Function):
         return dt, None, (dy if ctx.has_add else None), None
 
 
+class PeInterpFn(Function):
+    """OMREncoder.interpolate_pe (models.py:291-302): (Hin, Win, E) table -> (h*w, E) bilinear resampling; backward = transposed stencil."""
+
+    @staticmethod
+    def forward(ctx, table, h, w):
+        ctx.cfg = (int(h), int(w), tuple(table.shape))
+        return ops.pe_interp(table.detach().contiguous(), h, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, w, shp = ctx.cfg
+        return ops.pe_interp_bwd(dy.contiguous().float(), h, w, shp), None, None
+
+
 def pad_rows(packed, lens, fill_row=None):
     """Differentiable EG.pad_rows: (M,E) -> (B, Lmax, E) and mask; gradient of padded rows is dropped."""
     B, Lm, E, M = len(lens), max(lens), packed.shape[1], packed.shape[0]
@@ -460,18 +474,29 @@ def _grid_rows(h_p, w_p, Wm, dev):
 
 
 def _pe_rows(enc, table_param, dims, select=None):
-    """Differentiable pos_embedding[:h_p,:w_p] rows (optionally a subset per image) of every image, packed."""
+    """Differentiable pos_embedding[:h_p,:w_p] rows (optionally a subset per image) of every image, packed.  Grids beyond the table are
+    bilinearly interpolated (OMREncoder.batchify does so in every mode, models.py:315-318): their rows are appended to the gather table,
+    so the gradient reaches pos_embedding through PeInterpFn."""
     dev, E = table_param.device, table_param.shape[-1]
-    Wm = table_param.shape[1]
-    idx = []
+    Hm, Wm = table_param.shape[0], table_param.shape[1]
+    idx, extra = [], []
+    base = Hm * Wm
     for i, (h_p, w_p) in enumerate(dims):
-        if h_p > table_param.shape[0] or w_p > Wm:
-            raise NotImplementedError("PE interpolation in the training path is not built (inference path only)")
-        rows = _grid_rows(h_p, w_p, Wm, dev)
+        if h_p > Hm or w_p > Wm:
+            if not getattr(enc, "_allow_pe_interpolation", False):
+                raise ValueError(f"{h_p} x {w_p} image is too large for max positional embedding grid of shape {Hm} x {Wm}")
+            extra.append(PeInterpFn.apply(table_param, h_p, w_p))
+            rows = torch.arange(base, base + h_p * w_p, dtype=torch.int32, device=dev)
+            base += h_p * w_p
+        else:
+            rows = _grid_rows(h_p, w_p, Wm, dev)
         if select is not None:
             rows = rows[select[i].to(dev)]   # device gather: no host round trip per image
         idx.append(rows)
-    return GatherRowsFn.apply(table_param.reshape(-1, E), torch.cat(idx), None)
+    table = table_param.reshape(-1, E)
+    if extra:
+        table = torch.cat([table] + extra, 0)
+    return GatherRowsFn.apply(table, torch.cat(idx), None)
 
 
 def encoder_forward_packed(enc, x):
@@ -634,24 +659,24 @@ def mae_loss(pred, loss_mask, target):
 
 class CeLossFn(Function):
     @staticmethod
-    def forward(ctx, logits, target, ignore_index, count):
-        loss, dl = ops.ce_loss(logits, target, ignore_index, count, want_grad=True)
+    def forward(ctx, logits, target, ignore_index, count, label_smoothing=0.0):
+        loss, dl = ops.ce_loss(logits, target, ignore_index, count, want_grad=True, label_smoothing=label_smoothing)
         ctx.save_for_backward(dl)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
-        return dl * g, None, None, None
+        return dl * g, None, None, None, None
 
 
-def ce_loss(pred, target_seqs, pad_idx):
-    """OMRCELoss.forward (models.py:790-796): mean CE over non-pad targets."""
+def ce_loss(pred, target_seqs, pad_idx, label_smoothing=0.0):
+    """OMRCELoss.forward (models.py:784-796): mean CE over non-pad targets, nn.CrossEntropyLoss's label smoothing."""
     V = pred.shape[-1]
     lg = pred.reshape(-1, V).float().contiguous()
     tg = target_seqs.reshape(-1).to(device=lg.device, dtype=torch.int64).contiguous()
     count = float((tg != pad_idx).sum().item())
-    return CeLossFn.apply(lg, tg, pad_idx, count)
+    return CeLossFn.apply(lg, tg, pad_idx, count, float(label_smoothing))
 
 
 # ---- teacher-forced decoder (models.py:445-483) ---------------------------------------------------------------------------------

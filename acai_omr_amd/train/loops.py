@@ -60,19 +60,48 @@ def set_up_pretrain_optimizer(mae, epochs=PRETRAIN["epochs"], warmup_epochs=PRET
     return opt, cosine_anneal_with_warmup(opt, warmup_epochs, epochs, PRETRAIN["min_lr"])
 
 
-def pretrain_epoch(mae, dataloader, loss_fn, optimizer, scheduler, device):
-    """`pre_train.train_loop`: every batch is a full step; the scheduler moves once, after the last batch."""
+def _dp_scale(ddp, local_count, device):
+    """Data parallel: this rank's share of the batch-GLOBAL loss denominator (MAELoss / OMRCELoss divide by a batch-global count,
+    models.py:287,788) - scaled local losses + gradient SUM reproduce the single-process global-batch step for ragged shards."""
+    from ..dist import global_mean_scale
+    return global_mean_scale(float(local_count), group=ddp.group, device=device if torch.device(device).type == "cuda" else None)
+
+
+def _dp_mean_of(ddp, losses, device):
+    """Epoch average of the GLOBAL-batch losses: each entry is this rank's scaled share; one SUM all-reduce of the stacked vector."""
+    if not losses:
+        return 0.0
+    import torch.distributed as dist
+    v = torch.stack(losses).double()
+    if dist.is_initialized() and dist.get_world_size(ddp.group) > 1:
+        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=ddp.group)
+    return sum(v.cpu().tolist()) / len(losses)
+
+
+def pretrain_epoch(mae, dataloader, loss_fn, optimizer, scheduler, device, ddp=None):
+    """`pre_train.train_loop`: every batch is a full step; the scheduler moves once, after the last batch.
+    ddp (`dist.GradAllReduce` over `mae`, optional): `dataloader` yields this rank's shard of each global batch; the step is then the
+    single-process global-batch step (global-count loss scaling, bucketed gradient SUM all-reduce overlapped with backward)."""
     mae.train()
     losses = []
+    if ddp is not None:
+        ddp.zero_grad()
     for batch in dataloader:
         pred, loss_mask, target = mae(_on_device(batch, device))
         loss = loss_fn(pred, loss_mask, target)
+        if ddp is not None:
+            loss = loss * _dp_scale(ddp, loss_mask.sum().item(), device)
         losses.append(loss.detach())
         loss.backward()
+        if ddp is not None:
+            ddp.finish()
         optimizer.step()
-        optimizer.zero_grad()
+        if ddp is not None:
+            ddp.zero_grad()      # in place: gradients stay views of the all-reduce buckets
+        else:
+            optimizer.zero_grad()
     scheduler.step()
-    return _mean_of(losses)
+    return _dp_mean_of(ddp, losses, device) if ddp is not None else _mean_of(losses)
 
 
 def pretrain_validation(mae, dataloader, loss_fn, device):
@@ -154,24 +183,38 @@ def set_up_fine_tune_optimizer(vitomr, num_train_batches, epochs=FINE_TUNE["epoc
 
 
 def fine_tune_epoch(vitomr, dataloader, loss_fn, optimizer, scheduler, device, grad_accumulation_steps, tf_config, tf_scheduler, writer=None,
-                    counter=None):
+                    counter=None, ddp=None):
     """`omr_teacher_force_train.train_loop`: bf16 autocast forward_train + CE per batch, gradients accumulate (losses are NOT divided by the
     accumulation count, as in the reference), optimizer / LR scheduler / TF scheduler / counter move every `grad_accumulation_steps` batches
-    and on the last batch."""
+    and on the last batch.
+    ddp (`dist.GradAllReduce` over `vitomr`, optional): every batch is this rank's shard of a global micro-batch; micro-batches accumulate
+    locally (`no_sync`) and the gradients are all-reduced once, by the backward of the micro-batch that precedes the optimizer step."""
+    import contextlib
     vitomr.train()
     dev_type = torch.device(device).type
     losses, since_step = [], []
     n = len(dataloader)
+    if ddp is not None:
+        ddp.zero_grad()
     for i, batch in enumerate(dataloader):
+        stepping = (i + 1) % grad_accumulation_steps == 0 or i + 1 == n
         with torch.autocast(device_type=dev_type, dtype=torch.bfloat16):
             pred, target_seqs = vitomr.forward_train(_on_device(batch, device), tf_config.tf_prob, tf_config.tau, tf_config.use_hard_sampling)
             loss = loss_fn(pred, target_seqs)
-        losses.append(loss.detach())
-        since_step.append(loss.detach())
-        loss.backward()
-        if (i + 1) % grad_accumulation_steps == 0 or i + 1 == n:
+        if ddp is not None:
+            loss = loss * _dp_scale(ddp, (target_seqs != loss_fn.pad_idx).sum().item(), device)
+        losses.append(loss.detach().float())
+        since_step.append(loss.detach().float())
+        with (ddp.no_sync() if (ddp is not None and not stepping) else contextlib.nullcontext()):
+            loss.backward()
+        if stepping:
+            if ddp is not None:
+                ddp.finish()
             optimizer.step()
-            optimizer.zero_grad()
+            if ddp is not None:
+                ddp.zero_grad()
+            else:
+                optimizer.zero_grad()
             scheduler.step()
             tf_scheduler.step()
             if writer is not None:
@@ -184,7 +227,7 @@ def fine_tune_epoch(vitomr, dataloader, loss_fn, optimizer, scheduler, device, g
             since_step = []
             if counter is not None:
                 counter.increment()
-    return _mean_of(losses)
+    return _dp_mean_of(ddp, losses, device) if ddp is not None else _mean_of(losses)
 
 
 def fine_tune_validation(vitomr, dataloader, loss_fn, device):

@@ -69,25 +69,29 @@ def _center_crop(img, out_h, out_w):
     return img[..., top:top + out_h, left:left + out_w]
 
 
-def _device_image(img):
+def _device_image(img, device=None):
+    """GPU tensors stay on THEIR device; CPU tensors are uploaded to `device` (default: the current GPU)."""
     if not torch.is_tensor(img) or img.dim() != 3:
         raise TypeError("expected a C x H x W tensor (decode PIL images with ToImage / ToDtype first, as the reference pipelines do)")
     if not torch.cuda.is_available():
         raise RuntimeError("acai_omr_amd transforms run on the GPU (HIP resize kernel); there is no CPU fallback")
-    return img.to(device="cuda", dtype=torch.float32).contiguous()
+    if img.is_cuda:
+        return img.to(dtype=torch.float32).contiguous()
+    return img.to(device=device if device is not None else torch.device("cuda", torch.cuda.current_device()), dtype=torch.float32).contiguous()
 
 
 class PatchDivisibleResize(torch.nn.Module):
     """`PatchDivisibleResize` (acai_omr/utils/utils.py:309-330): resize to the nearest lower patch-divisible size, bicubic + antialias, on the GPU.
     Takes a C x H x W tensor (CPU tensors are uploaded once); returns a GPU tensor."""
 
-    def __init__(self, patch_size):
+    def __init__(self, patch_size, device=None):
         super().__init__()
         self.patch_size = patch_size
+        self.device = device   # extension: target GPU for CPU inputs (default: the current device)
 
     def forward(self, img):
         from . import ops
-        img = _device_image(img)
+        img = _device_image(img, self.device)
         _, h, w = img.shape
         new_w = max(w // self.patch_size * self.patch_size, self.patch_size)
         new_h = max(h // self.patch_size * self.patch_size, self.patch_size)
@@ -100,8 +104,9 @@ class DynamicResize(torch.nn.Module):
     the clamp in one HIP launch pair on the GPU.  Takes the float C x H x W tensor the reference's `ToImage -> ToDtype(float32, scale=True)`
     produce (a CPU tensor is uploaded once; this replaces the per-example `.to(device)` of `pre_train.py:56`) and returns a GPU tensor."""
 
-    def __init__(self, patch_size, max_seq_len, pe_max_height, pe_max_width, crop_imgs):
+    def __init__(self, patch_size, max_seq_len, pe_max_height, pe_max_width, crop_imgs, device=None):
         super().__init__()
+        self.device = device   # extension: target GPU for CPU inputs (default: the current device)
         self.patch_size = patch_size
         self.max_seq_len = max_seq_len
         self.pe_max_height = pe_max_height
@@ -110,7 +115,7 @@ class DynamicResize(torch.nn.Module):
 
     def forward(self, img):
         from . import ops
-        img = _device_image(img)
+        img = _device_image(img, self.device)
         target_height, target_width = dynamic_resize_target(img.shape[-2], img.shape[-1], self.patch_size, self.max_seq_len)
         img = ops.resize_bicubic_aa(img, (target_height, target_width), clamp01=True)
         if self.crop_imgs:

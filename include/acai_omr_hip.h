@@ -85,6 +85,13 @@ int acai_resize_bicubic_aa(const float *img, int C, int H, int W, float *tmp, fl
  * MAE shuffle / restore index_select (M:114,123,229). table/out fp32. */
 int acai_gather_rows(const float *table, const int32_t *idx, const float *add, float *out, int rows, int dim, void *stream);
 
+/* OMREncoder.interpolate_pe (M:291-302): F.interpolate(pos_embedding (Hin,Win,E) as NCHW, size=(Hout,Wout), mode="bilinear",
+ * align_corners=False), result (Hout*Wout, E) row-major - aten's upsample_bilinear2d arithmetic (source index (dst + 0.5) * in/out - 0.5
+ * clamped at 0, neighbour clamped at in-1).  bwd: dtable[Hin*Win, E] += the transposed stencil applied to dout (float atomics; dtable is
+ * NOT zeroed here). */
+int acai_pe_interp_fwd(const float *table, int Hin, int Win, int E, float *out, int Hout, int Wout, void *stream);
+int acai_pe_interp_bwd(const float *dout, int Hout, int Wout, int E, float *dtable, int Hin, int Win, void *stream);
+
 /* autocast's fp32 -> bf16 input cast (round to nearest even) for an activation that feeds a bf16 GEMM. */
 int acai_cast_f32_bf16(const float *x, void *y, int64_t n, void *stream);
 
@@ -130,9 +137,10 @@ int acai_dropout_add(const void *x, const float *residual, void *out, int rows, 
  * dpred (may be NULL) = d loss / d pred; that = (target - mean) / sqrt(var_unbiased + 1e-6). */
 int acai_mae_loss(const float *pred, const float *target, const unsigned char *mask, float inv_count, float *loss, float *dpred,
                   int rows, int dim, void *stream);
-/* OMRCELoss (M:784-796) forward + backward: mean cross entropy over rows whose target != ignore_index. */
-int acai_ce_loss(const float *logits, int ld, const int64_t *target, int ignore_index, float inv_count, float *loss, float *dlogits,
-                 int rows, int V, void *stream);
+/* OMRCELoss (M:784-796) forward + backward: mean cross entropy over rows whose target != ignore_index, with nn.CrossEntropyLoss's
+ * label_smoothing (M:786-788; 0 = plain NLL). */
+int acai_ce_loss(const float *logits, int ld, const int64_t *target, int ignore_index, float inv_count, float label_smoothing, float *loss,
+                 float *dlogits, int rows, int V, void *stream);
 
 /* Fused multi-tensor AdamW: one launch steps every parameter tensor (reference: torch.optim.AdamW in acai_omr/train/pre_train.py:105 and
  * omr_teacher_force_train.py:207 over the param groups of acai_omr/models/models.py:761-781; the cosine/warm-up schedule of
@@ -146,9 +154,10 @@ typedef struct AcaiAdamWTensor {
     float *m, *v;
     int64_t n;
     int32_t group, pad_;
+    float bias_c1, bias_c2_sqrt; /* 1 - beta1^t, sqrt(1 - beta2^t) with THIS tensor's step count t (torch keeps `step` per parameter) */
 } AcaiAdamWTensor;
 typedef struct AcaiAdamWGroup {
-    float lr, beta1, beta2, eps, weight_decay, bias_c1, bias_c2_sqrt, pad_;
+    float lr, beta1, beta2, eps, weight_decay, pad0_, pad1_, pad2_;
 } AcaiAdamWGroup;
 int acai_adamw_step(const AcaiAdamWTensor *tensors, const AcaiAdamWGroup *groups, const int32_t *chunk_tensor, const int64_t *chunk_off,
                     int n_chunks, int chunk_elems, float grad_scale, void *stream);

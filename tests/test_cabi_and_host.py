@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     import ctypes
     assert ctypes.sizeof(_lib.AcaiDecLayer) == 8 * len(names)
     assert ctypes.sizeof(_lib.AcaiDecoder) == 20 * 4 + 8 * 23
-    assert ctypes.sizeof(_lib.AcaiAdamWTensor) == 48 and ctypes.sizeof(_lib.AcaiAdamWGroup) == 32   # include/acai_omr_hip.h: AcaiAdamWTensor / AcaiAdamWGroup
+    assert ctypes.sizeof(_lib.AcaiAdamWTensor) == 56 and ctypes.sizeof(_lib.AcaiAdamWGroup) == 32   # include/acai_omr_hip.h: AcaiAdamWTensor / AcaiAdamWGroup
 
 
 def test_ops_refuse_cpu_tensors():

@@ -83,3 +83,128 @@ def test_shard_by_cost_balances_ragged_batch():
     assert sorted(i for p in parts for i in p) == list(range(32))
     loads = [sum(costs[i] for i in p) for p in parts]
     assert max(loads) - min(loads) <= 1024 and all(len(p) == 4 for p in parts)
+
+
+# ---- the training loops under data parallelism (acai_omr_amd/train/loops.py with ddp=GradAllReduce) ---------------------------------------
+class _ToyMAE(torch.nn.Module):
+    """Stands in for the HIP MAE on the CPU: same call contract (batch of (image, target) -> pred, loss_mask, target), ragged batches."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.net = torch.nn.Sequential(torch.nn.Linear(8, 12), torch.nn.GELU(), torch.nn.Linear(12, 8))
+        self.unused = torch.nn.Parameter(torch.zeros(3))   # never receives a gradient: its bucket is reduced by finish()
+
+    def forward(self, batch):
+        xs = torch.stack([x for x, _ in batch])
+        mask = torch.stack([y for _, y in batch])
+        return self.net(xs), mask, xs
+
+
+def _toy_mae_loss(pred, loss_mask, target):
+    per = ((pred - target) ** 2).mean(-1)
+    return (per * loss_mask).sum() / loss_mask.sum()
+
+
+class _ToyTF(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(4)
+        self.emb = torch.nn.Embedding(11, 6)
+        self.out = torch.nn.Linear(6, 11)
+
+    def forward_train(self, batch, tf_prob, tau, hard):
+        seqs = torch.stack([y for _, y in batch])
+        with torch.autocast("cpu", enabled=False):   # the loop runs under autocast(bf16): keep the toy exact (bf16 GEMMs round per shard)
+            return self.out(self.emb(seqs[:, :-1])), seqs[:, 1:]
+
+
+class _ToyCE(torch.nn.Module):
+    pad_idx = 1
+
+    def forward(self, pred, tgt):
+        return torch.nn.functional.cross_entropy(pred.reshape(-1, pred.shape[-1]).float(), tgt.reshape(-1), ignore_index=1)
+
+
+def _toy_data():
+    g = torch.Generator().manual_seed(9)
+    mae_batches = [[(torch.randn(8, generator=g), (torch.rand(1, generator=g) > 0.3).float().squeeze(0)) for _ in range(n)] for n in (6, 5, 7)]
+    for b in mae_batches:     # at least one masked row per shard
+        b[0] = (b[0][0], torch.tensor(1.0))
+        b[-1] = (b[-1][0], torch.tensor(1.0))
+    tf_batches = []
+    for n in (5, 6, 4):
+        rows = []
+        for _ in range(n):
+            s = torch.randint(2, 11, (7,), generator=g)
+            s[int(torch.randint(3, 7, (1,), generator=g)):] = 1    # ragged <pad> tails: different non-pad counts per shard
+            rows.append((torch.zeros(1), s))
+        tf_batches.append(rows)
+    return mae_batches, tf_batches
+
+
+class _L(list):
+    pass
+
+
+def _run_loops(model_mae, model_tf, mae_batches, tf_batches, ddp_mae=None, ddp_tf=None, set_to_none=False):
+    from acai_omr_amd.train import loops
+    from acai_omr_amd.utils import cosine_anneal_with_warmup
+    opt = torch.optim.SGD(model_mae.parameters(), lr=0.1)   # (SGD: AdamW's normalised update amplifies rounding of ~0 gradients)
+    sch = cosine_anneal_with_warmup(opt, 1, 4, 1e-6)
+    if set_to_none:
+        opt.zero_grad(set_to_none=True)      # drops the bucket views: the hooks must re-attach
+    avg_mae = loops.pretrain_epoch(model_mae, _L(mae_batches), _toy_mae_loss, opt, sch, "cpu", ddp=ddp_mae)
+    opt2 = torch.optim.SGD(model_tf.parameters(), lr=0.1)
+    sch2 = cosine_anneal_with_warmup(opt2, 1, 4, 1e-6, num_train_batches=2)
+    cfg = loops.TFConfig(1.0, 5.0, False)
+    tfs = loops.TFScheduler(cfg, 1.0, 1.0, 5.0, 0.1, 1, 2, 2)
+    avg_tf = loops.fine_tune_epoch(model_tf, _L(tf_batches), _ToyCE(), opt2, sch2, "cpu", 2, cfg, tfs, ddp=ddp_tf)
+    return avg_mae, avg_tf
+
+
+def _loop_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    from acai_omr_amd.dist import GradAllReduce
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mae_batches, tf_batches = _toy_data()
+    cut = lambda b: b[: len(b) // 2 + 1] if rank == 0 else b[len(b) // 2 + 1:]   # noqa: E731  ragged shards
+    m1, m2 = _ToyMAE(), _ToyTF()
+    d1, d2 = GradAllReduce(m1, bucket_mb=0.0003), GradAllReduce(m2, bucket_mb=0.0003)
+    avg = _run_loops(m1, m2, [cut(b) for b in mae_batches], [cut(b) for b in tf_batches], d1, d2, set_to_none=True)
+    # a second synchronising backward without finish() must be refused, not silently double-reduced
+    d1.zero_grad()
+    pred, lm, tgt = m1(cut(mae_batches[0]))
+    _toy_mae_loss(pred, lm, tgt).backward()
+    try:
+        pred, lm, tgt = m1(cut(mae_batches[0]))
+        _toy_mae_loss(pred, lm, tgt).backward()
+        refused = False
+    except RuntimeError:
+        refused = True
+    d1.finish()
+    if rank == 0:
+        torch.save((avg, [p.detach().clone() for p in m1.parameters()], [p.detach().clone() for p in m2.parameters()], refused), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_training_loops_under_two_ranks_match_single_process(tmp_path):
+    """pretrain_epoch / fine_tune_epoch with ddp=GradAllReduce on 2 gloo ranks and ragged shards == the same loops on the whole batches in
+    one process: losses and parameters after the epoch (per-batch steps; accumulation of 2 with a flush), with an optimizer.zero_grad(
+    set_to_none=True) beforehand (the ADVICE case: dropped bucket views must be re-attached by the hooks)."""
+    out = str(tmp_path / "l.pt")
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_loop_worker, args=(2, port, out), nprocs=2, join=True)
+    avg, p1, p2, refused = torch.load(out)
+    sys.path.insert(0, ROOT)
+    mae_batches, tf_batches = _toy_data()
+    m1, m2 = _ToyMAE(), _ToyTF()
+    ref = _run_loops(m1, m2, mae_batches, tf_batches)
+    assert refused
+    assert abs(avg[0] - ref[0]) < 1e-5 and abs(avg[1] - ref[1]) < 1e-5, (avg, ref)
+    for a, b in zip(p1, m1.parameters()):
+        assert torch.allclose(a, b.detach(), atol=2e-5), float((a - b.detach()).abs().max())
+    for a, b in zip(p2, m2.parameters()):
+        assert torch.allclose(a, b.detach(), atol=2e-5), float((a - b.detach()).abs().max())
