@@ -124,13 +124,13 @@ def test_config2_mae_bf16_step_at_size_vs_oracle(dev):
     assert torch.equal(loss_mask.cpu(), lm_o)
     e_pred = md(pred, pred_o)
     print(f"config2 at size: loss {float(loss):.5f} oracle {float(loss_o):.5f}  pred max|d| {e_pred:.3e}")
-    assert abs(float(loss) - float(loss_o)) < 1e-2 * max(1.0, abs(float(loss_o)))
+    assert abs(float(loss) - float(loss_o)) < 2e-3 * max(1.0, abs(float(loss_o)))     # measured 1e-5
     assert e_pred < 0.06 * max(1.0, float(pred_o.abs().max()))
     params = dict(mae.named_parameters())
     for n in names:
         r, c = relerr(params[n].grad, sd[n].grad), cosine(params[n].grad, sd[n].grad)
         print(f"  grad {n}: rel max err {r:.3e} cosine {c:.6f}")
-        assert r < 0.1 and c > 0.99, (n, r, c)
+        assert r < 2e-2 and c > 0.9999, (n, r, c)            # measured 6e-4 ... 3e-3, cosine 0.999998
 
 
 # ---- config 3 ------------------------------------------------------------------------------------------------------------------------
@@ -169,13 +169,13 @@ def test_config3_teacher_forced_bf16_step_at_size_vs_oracle(dev):
     valid = tgt_o != 1
     e_pred = md(pred.float().cpu()[valid], pred_o.detach()[valid])
     print(f"config3 at size: loss {float(loss):.5f} oracle {float(loss_o):.5f}  logits max|d| {e_pred:.3e} (|logit| max {float(pred_o.abs().max()):.2f})")
-    assert abs(float(loss) - float(loss_o)) < 1e-2 * max(1.0, abs(float(loss_o)))
+    assert abs(float(loss) - float(loss_o)) < 2e-3 * max(1.0, abs(float(loss_o)))     # measured 3e-4
     assert e_pred < 0.05 * max(1.0, float(pred_o.abs().max()))
     params = dict(m.named_parameters())
     for n in names:
         r, c = relerr(params[n].grad, sd[n].grad), cosine(params[n].grad, sd[n].grad)
         print(f"  grad {n}: rel max err {r:.3e} cosine {c:.6f}")
-        assert r < 0.12 and c > 0.99, (n, r, c)
+        assert r < 2e-2 and c > 0.9999, (n, r, c)            # measured 3e-3 ... 5e-3, cosine 0.999996
 
 
 @pytest.mark.parametrize("name", ["tf_small", "tf_dh64"])
@@ -316,16 +316,16 @@ def test_grpo_rollouts_replay_the_reference(dev, name, tag, grouped):
         assert torch.equal(ro.cpu(), rro) and torch.equal(mk.cpu(), rmk)
         assert md(lp, rlp) < 1e-4
     else:
-        # bf16 logits differ from the reference's by accumulation order: a draw may fall on the other side of a CDF step.  Rows must agree
-        # up to such a step, and log-probs of agreeing live positions to two bf16 ulps (aten's bf16 log_softmax is not "fp32, rounded once")
+        # bf16 logits differ from the reference's by accumulation order (one bf16 ulp at |logit| ~ 4-8 is 0.03): a draw may fall on the other
+        # side of a CDF step.  Rows must agree up to such a step, and the log-probs of agreeing live positions to that logit resolution (the
+        # sampling formula itself is held to the oracle on the path's OWN logits in test_gpu_parity.py::test_grpo_rollout_policy_sampling)
         n = min(ro.shape[1], rro.shape[1])
         same = ro.cpu()[:, :n] == rro[:, :n]
         agree = same.int().cumprod(dim=1).bool()
         assert float(agree.float().mean()) > 0.7
         live = agree & rmk[:, :n] & mk.cpu()[:, :n]
         d = (lp.cpu()[:, :n] - rlp[:, :n]).abs()[live]
-        ulp = torch.exp2(torch.floor(torch.log2(rlp[:, :n][live].abs().clamp(min=2.0 ** -126))) - 7)
-        assert bool((d <= 2 * ulp + 1e-6).all()), float(d.max())
+        assert float(d.max()) < 0.07, float(d.max())
 
 
 # ---- small holes: PE interpolation in the training path, label smoothing, the reference's micro-config --------------------------------------
