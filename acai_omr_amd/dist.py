@@ -145,3 +145,104 @@ class GradAllReduce:
         self._handles = []
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+
+
+# ---- self-check of the data-parallel step on the REAL path (HIP autograd Functions + GradAllReduce + FusedAdamW) ---------------------------
+def dp_parity_check(golden_dir, vocab_path, device, group=None):
+    """Every rank trains the tiny MAE and the tiny teacher-forced ViTOMR of tests/golden/{mae_small,tf_small}.pt on ITS ragged shard of a
+    global batch (global-count loss scaling, bucketed gradient all-reduce, `no_sync` accumulation for the teacher-forced step, fused AdamW)
+    and, beside it, the single-process step on the whole global batch; returns the largest |difference| of gradients (relative to the
+    tensor's largest gradient) and of the AdamW-updated parameters (relative to lr, on the elements whose gradient is not ~0: AdamW's
+    normalised update turns rounding noise on a ~0 gradient into a +-lr move on either side) - fp32: ~1e-5.  Called by `bench.py --gpus N` (field `dp_parity_max_abs_diff`)
+    and by the 2-rank GPU test; needs an initialised process group (or none: world size 1)."""
+    import os
+
+    from .models.models import MAE, FineTuneOMREncoder, MAELoss, OMRCELoss, OMRDecoder, TeacherForcedViTOMR
+    from .optim import FusedAdamW
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    dev = torch.device(device)
+    worst = 0.0
+
+    def compare(m_dp, m_ref):
+        nonlocal worst
+        for (n, a), (_, b) in zip(m_dp.named_parameters(), m_ref.named_parameters()):
+            if b.grad is None:
+                continue
+            worst = max(worst, float((a.grad - b.grad).abs().max()) / max(1e-12, float(b.grad.abs().max())))
+
+    def compare_params(m_dp, m_ref, lr):
+        nonlocal worst
+        for (n, a), (_, b) in zip(m_dp.named_parameters(), m_ref.named_parameters()):
+            if b.grad is None:
+                continue
+            solid = b.grad.abs() > 1e-3 * b.grad.abs().max()
+            if bool(solid.any()):
+                worst = max(worst, float((a.detach() - b.detach()).abs()[solid].max()) / lr)
+
+    # ---- MAE: 2 * world images (the fixture's three, cycled, each with its own noise), dealt by patch count
+    fx = torch.load(os.path.join(golden_dir, "mae_small.pt"), map_location="cpu", weights_only=False)
+    cfg = fx["cfg"]
+    n_items = 2 * world + 1
+    items = [(fx["imgs"][i % 3].to(dev), fx["tgts"][i % 3].to(dev), fx["noises"][i % 3].roll(i // 3)) for i in range(n_items)]
+    costs = [it[0].shape[-1] * it[0].shape[-2] for it in items]
+    mine = shard_by_cost(costs, world)[rank]
+
+    def build_mae():
+        m = MAE(cfg["mask_ratio"], cfg["P"], cfg["pe_h"], cfg["pe_w"], encoder_hidden_dim=cfg["enc_dim"], decoder_hidden_dim=cfg["dec_dim"],
+                encoder_kwargs=cfg["enc_kwargs"], decoder_kwargs=cfg["dec_kwargs"])
+        m.load_state_dict(fx["state_dict"])
+        return m.to(dev).train()
+
+    ref, dp = build_mae(), build_mae()
+    pred, lm, tgt = ref([(a, b) for a, b, _ in items], noises=[c for _, _, c in items])
+    MAELoss()(pred, lm, tgt).backward()
+    ddp = GradAllReduce(dp, bucket_mb=0.01, group=group)
+    ddp.zero_grad()
+    pred, lm, tgt = dp([(items[i][0], items[i][1]) for i in mine], noises=[items[i][2] for i in mine])
+    (MAELoss()(pred, lm, tgt) * global_mean_scale(float(lm.sum().item()), group=group, device=dev)).backward()
+    ddp.finish()
+    compare(dp, ref)
+    for m in (ref, dp):
+        FusedAdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05).step()
+    compare_params(dp, ref, 1e-3)
+
+    # ---- teacher-forced ViTOMR: two micro-batches accumulated (summed losses, omr_teacher_force_train.py:117-128), one all-reduce
+    fx = torch.load(os.path.join(golden_dir, "tf_small.pt"), map_location="cpu", weights_only=False)
+    cfg = fx["cfg"]
+
+    def build_tf():
+        enc = FineTuneOMREncoder(cfg["P"], cfg["pe_h"], cfg["pe_w"], cfg["ft_depth"], num_layers=cfg["enc_layers"], hidden_dim=cfg["enc_dim"],
+                                 num_heads=cfg["enc_heads"], mlp_dim=cfg["enc_mlp"], transformer_dropout=0.0)
+        dec = OMRDecoder(cfg["max_len"], vocab_path, num_layers=cfg["dec_layers"], hidden_dim=cfg["dec_dim"], num_heads=cfg["dec_heads"],
+                         mlp_dim=cfg["dec_mlp"], transformer_dropout=0.0)
+        m = TeacherForcedViTOMR(enc, None, dec, transition_head_dim=cfg["head_dim"], transition_head_dropout=0.0)
+        m.load_state_dict(fx["state_dict"])
+        return m.to(dev).train()
+
+    ref, dp = build_tf(), build_tf()
+    ce = OMRCELoss(ref.decoder.pad_idx)
+    micro = []
+    for mb in range(2):
+        its = [(fx["imgs"][(i + mb) % 3].to(dev), fx["lmx"][(i + 2 * mb) % 3].to(dev)) for i in range(2 * world + 1 - mb)]
+        micro.append(its)
+    for its in micro:
+        pred, tgt = ref(its)
+        ce(pred, tgt).backward()
+    ddp = GradAllReduce(dp, bucket_mb=0.01, group=group)
+    ddp.zero_grad()
+    for k, its in enumerate(micro):
+        sel = shard_by_cost([it[0].shape[-1] * it[0].shape[-2] + 64 * it[1].numel() for it in its], world)[rank]
+        pred, tgt = dp([its[i] for i in sel])
+        loss = ce(pred, tgt) * global_mean_scale(float((tgt != ref.decoder.pad_idx).sum().item()), group=group, device=dev)
+        if k + 1 < len(micro):
+            with ddp.no_sync():
+                loss.backward()
+        else:
+            loss.backward()
+    ddp.finish()
+    compare(dp, ref)
+    t = torch.tensor([worst], dtype=torch.float64, device=dev)
+    if dist.is_initialized() and world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())

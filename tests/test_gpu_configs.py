@@ -543,3 +543,23 @@ def test_ops_follow_the_operands_device(dev):
         x = torch.randn(8, 256, device=dev)
         y, _ = ops.layernorm(x, torch.ones(256, device=dev), torch.zeros(256, device=dev), 1e-5)
         assert md(y, torch.nn.functional.layer_norm(x, (256,))) < 1e-5
+
+
+def test_data_parallel_step_on_the_hip_path_two_ranks(dev):
+    """`GradAllReduce` + global-count loss scaling + `no_sync` accumulation + fused AdamW on the REAL path (HIP autograd Functions) under two
+    ranks with ragged shards == the single-process global-batch step (gradients and updated parameters).  Two processes started by
+    torch.distributed.run (before anything of theirs touches the GPU) share this box's one card over gloo; on the 8-GPU node the same
+    function runs over RCCL inside `bench.py --gpus N` (`dp_parity_max_abs_diff`)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29700 + os.getpid() % 200
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "tools", "dp_parity.py"), "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["world"] == 2 and out["dp_parity_max_abs_diff"] < 1e-4, out
