@@ -71,6 +71,7 @@ _SIGNATURES = {
     "acai_scatter_add_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "acai_mae_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "acai_ce_loss": (c_int, [c_void_p, c_int, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "acai_debug_stamps": (c_int, [c_void_p, c_int]),
     "acai_pe_interp_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "acai_pe_interp_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "acai_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),

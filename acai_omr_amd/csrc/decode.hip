@@ -42,7 +42,12 @@ struct SkinnyArgs {
     int x_bf16, y_bf16;      // activation in / out stored as bf16 (x: row stride ldx in bf16 elements)
     int rows_per_block;      // MFMA kernel: weight rows per workgroup (set by the launcher)
     int w_cached;            // non-zero: default-policy (cacheable) weight loads instead of non-temporal ones (ACAI_SKINNY_NT, an A/B aid)
+    unsigned long long *stamps;   // diagnostic (acai_debug_stamps): [workgroup][8] s_memrealtime stamps (100 MHz) of the kernel's stages, else null
 };
+
+// diagnostic stamp buffer: [launch][1024 workgroups][8] (tools/stamp_decode.py); one slot per skinny launch, handed out in launch order
+static unsigned long long *g_stamps = nullptr;
+static int g_stamp_cap = 0, g_stamp_next = 0;
 
 template <typename TW, bool FAST>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
@@ -178,6 +183,10 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
     const bf16_t *Wrow = reinterpret_cast<const bf16_t *>(a.W) + (size_t)(row_ok ? n0 + r : 0) * a.ldw + kbase + 8 * q;
     float *red = reinterpret_cast<float *>(smem);              // [NW][256] floats
     unsigned char *xs = smem + NW * 1024;                      // [rows][pitch] bf16 activation image
+    auto stamp = [&](int k) {
+        if (a.stamps && tid == 0) a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
 
     // batch tiles of 16 rows: one per workgroup along grid.y (B > 16: GRPO rollouts, max_batch_size = 32 inference) - the tiles of a weight
     // row block re-read its weights from L2 instead of queueing four latency chains inside one workgroup (64 rows: 24 -> 17 us per launch)
@@ -335,7 +344,9 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
         }
         request_weights();   // waves without an activation row of this tile
         request_epilogue();
+        stamp(1);
         __syncthreads();
+        stamp(2);
         // 3. MFMA over this wave's K slice; batch columns >= nb read row 0 (their outputs are never stored)
         const unsigned char *xfrag = xs + (r < nb ? r : 0) * pitch + (kbase + 8 * q) * 2;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -358,7 +369,9 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) red[wave * 256 + lane * 4 + i] = acc[i];
+        stamp(3);
         __syncthreads();
+        stamp(4);
         if (wave == 0) {
             // D layout: col (batch) = lane & 15, row (weight row) = 4 * (lane >> 4) + i
             const int b = bt + r;
@@ -388,8 +401,202 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
                     a.y[(size_t)b * a.ldy + n] = v;
             }
         }
+        stamp(5);
         __syncthreads();
     }
+}
+
+// ---- the decode chain's GEMV at its two hot shapes (K = 256 * NW: K = 1024 fp32 activations, K = 4096 bf16 activations) ------------------
+// Same arithmetic and fusions as skinny_mfma_kernel (bit-identical results), rebuilt around what in-kernel stamps showed on MI355X
+// (tools/stamp_decode.py): of a 5-7 us launch, 2.7-5.2 us passed before the activation image was complete and ~1 us in the epilogue, because
+//   * the compiler fetched the 200-byte argument struct in SIX dependent scalar-load stages (each a cold round trip after a kernel boundary):
+//     here every argument is forced into SGPRs by one batch of s_loads and one wait;
+//   * loads sat inside per-lane branches, so the first use of the activation rows waited with vmcnt(0) for the weight fragments (HBM) and the
+//     epilogue operands as well: here every load is unconditional (clamped address, or a buffer load whose out-of-range lanes return zero), in
+//     straight-line code, so the compiler's counted waits are exact - activations first, weights stay in flight across the barrier, epilogue
+//     operands are requested after the barrier and land under the weight wait;
+//   * one wave reduced and finished all 4 x 64 outputs: here wave i finishes accumulator register i of every lane (4 waves in parallel).
+typedef __attribute__((vector_size(16))) unsigned int skm_v4u;
+
+template <bool XBF16, bool HAS_LN, int NW>
+__global__ __launch_bounds__(64 * NW) void skinny_chain_kernel(SkinnyArgs a) {
+    constexpr int K = 256 * NW, PITCH = K * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    asm volatile("" ::"s"(a.x), "s"(a.W), "s"(a.bias), "s"(a.residual), "s"(a.y), "s"(a.ldx), "s"(a.ldw), "s"(a.ldr), "s"(a.ldy), "s"(a.B), "s"(a.N),
+                 "s"(a.flags), "s"(a.k_cache), "s"(a.v_cache), "s"(a.step));
+    asm volatile("" ::"s"(a.E), "s"(a.H), "s"(a.dh), "s"(a.dhp), "s"(a.Tmax), "s"(a.ln_w), "s"(a.ln_b), "s"(a.ln_eps), "s"(a.stats_out), "s"(a.rln_w),
+                 "s"(a.rln_b), "s"(a.rstats), "s"(a.y_bf16), "s"(a.rows_per_block), "s"(a.stamps));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int R = a.rows_per_block, n0 = blockIdx.x * R, bt = blockIdx.y * 16;
+    const int nb = min(16, a.B - bt);
+    float *red = reinterpret_cast<float *>(smem);   // [NW][256]
+    unsigned char *xs = smem + NW * 1024;           // [rows][PITCH] bf16 activation image
+    auto stamp = [&](int k) {
+        if (a.stamps && tid == 0) a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
+
+    // weight fragments: lane (r, q) of wave w owns 8 x 16 B of row n0 + r at k = 256 w + 8 q + 32 c.  Buffer loads: lanes without a row are
+    // out of range and read zeros - no branch.  Non-temporal: every weight byte is read once per step.
+    const bool row_ok = r < R && n0 + r < a.N;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.W), 0, (int)((size_t)a.N * a.ldw * 2), 0x00020000);
+    const unsigned woff = row_ok ? (unsigned)(((size_t)(n0 + r) * a.ldw + wave * 256 + 8 * q) * 2) : 0xFFF00000u;
+    skm_v4u wf[8];
+    auto request_weights = [&]() {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) wf[c] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, woff + 64 * c, 0, 2);
+    };
+
+    if constexpr (XBF16) {
+        // activation rows are bf16 already: the [nb][K] image is copied in half-row chunks (4 KB), wave w takes chunk w (and w + 16 when the
+        // tile has more than 8 rows): every wave has 4 loads in flight, none idles.  A wave without a chunk copies chunk 0 again (same bytes
+        // to the same place) instead of branching around its loads.
+        static_assert(!XBF16 || NW == 16, "bf16 activations: K = 4096");
+        auto copy = [&](int ch, bool first) {
+            const int c = ch < 2 * nb ? ch : 0;
+            const bf16_t *xr = reinterpret_cast<const bf16_t *>(a.x) + (size_t)(bt + (c >> 1)) * a.ldx + (c & 1) * (K / 2) + lane * 8;
+            unsigned char *xd = xs + (c >> 1) * PITCH + ((c & 1) * (K / 2) + lane * 8) * 2;
+            static_assert(!XBF16 || K == 4096, "four 16-byte pieces per lane and chunk");   // (named registers: an array here went to scratch)
+            const uint4 x0 = *reinterpret_cast<const uint4 *>(xr), x1 = *reinterpret_cast<const uint4 *>(xr + 512),
+                        x2 = *reinterpret_cast<const uint4 *>(xr + 1024), x3 = *reinterpret_cast<const uint4 *>(xr + 1536);
+            if (first) request_weights();
+            __builtin_amdgcn_sched_barrier(0);
+            *reinterpret_cast<uint4 *>(xd) = x0;
+            *reinterpret_cast<uint4 *>(xd + 1024) = x1;
+            *reinterpret_cast<uint4 *>(xd + 2048) = x2;
+            *reinterpret_cast<uint4 *>(xd + 3072) = x3;
+        };
+        copy(wave, true);
+        if (nb > 8) copy(wave + 16, false);
+    } else {
+        static_assert(XBF16 || NW == 4, "fp32 activations: K = 1024");
+        // wave w builds rows w and w + 4 (then w + 8, w + 12 when the tile has more than 8 rows); lane takes 4 consecutive k per 256
+        auto build = [&](int ra, int rb, bool first) {
+            const bool oka = ra < nb, okb = rb < nb;
+            const float *pa = a.x + (size_t)(bt + (oka ? ra : 0)) * a.ldx + lane * 4, *pb = a.x + (size_t)(bt + (okb ? rb : 0)) * a.ldx + lane * 4;
+            float4 va[4], vb[4], lw[4], lb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                va[j] = *reinterpret_cast<const float4 *>(pa + j * 256);
+                vb[j] = *reinterpret_cast<const float4 *>(pb + j * 256);
+            }
+            if constexpr (HAS_LN) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    lw[j] = *reinterpret_cast<const float4 *>(a.ln_w + j * 256 + lane * 4);
+                    lb[j] = *reinterpret_cast<const float4 *>(a.ln_b + j * 256 + lane * 4);
+                }
+            }
+            if (first) request_weights();   // behind this wave's activation rows: loads return in issue order
+            __builtin_amdgcn_sched_barrier(0);   // every load above is in flight before anything is waited for (hipcc otherwise sinks the LN / weight loads below the statistics)
+            if constexpr (HAS_LN) {
+                // both rows' sum and sum of squares ride the same 6 cross-lane steps; one-pass variance (as skinny_mfma_kernel)
+                float t0 = 0.f, u0 = 0.f, t1 = 0.f, u1 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    t0 += (va[j].x + va[j].y) + (va[j].z + va[j].w);
+                    u0 += (va[j].x * va[j].x + va[j].y * va[j].y) + (va[j].z * va[j].z + va[j].w * va[j].w);
+                    t1 += (vb[j].x + vb[j].y) + (vb[j].z + vb[j].w);
+                    u1 += (vb[j].x * vb[j].x + vb[j].y * vb[j].y) + (vb[j].z * vb[j].z + vb[j].w * vb[j].w);
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    t0 += __shfl_xor(t0, o);
+                    u0 += __shfl_xor(u0, o);
+                    t1 += __shfl_xor(t1, o);
+                    u1 += __shfl_xor(u1, o);
+                }
+                const float invK = 1.0f / (float)K;
+                const float m0 = t0 * invK, m1 = t1 * invK;
+                const float s0 = 1.0f / sqrtf(fmaxf(u0 * invK - m0 * m0, 0.f) + a.ln_eps), s1 = 1.0f / sqrtf(fmaxf(u1 * invK - m1 * m1, 0.f) + a.ln_eps);
+                if (lane == 0 && a.stats_out && blockIdx.x == 0) {
+                    if (oka) {
+                        a.stats_out[(bt + ra) * 2] = m0;
+                        a.stats_out[(bt + ra) * 2 + 1] = s0;
+                    }
+                    if (okb) {
+                        a.stats_out[(bt + rb) * 2] = m1;
+                        a.stats_out[(bt + rb) * 2 + 1] = s1;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    va[j].x = (va[j].x - m0) * s0 * lw[j].x + lb[j].x; va[j].y = (va[j].y - m0) * s0 * lw[j].y + lb[j].y;
+                    va[j].z = (va[j].z - m0) * s0 * lw[j].z + lb[j].z; va[j].w = (va[j].w - m0) * s0 * lw[j].w + lb[j].w;
+                    vb[j].x = (vb[j].x - m1) * s1 * lw[j].x + lb[j].x; vb[j].y = (vb[j].y - m1) * s1 * lw[j].y + lb[j].y;
+                    vb[j].z = (vb[j].z - m1) * s1 * lw[j].z + lb[j].z; vb[j].w = (vb[j].w - m1) * s1 * lw[j].w + lb[j].w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kb = (j * 256 + lane * 4) * 2;
+                if (oka) *reinterpret_cast<uint2 *>(xs + ra * PITCH + kb) = make_uint2(pack_bf16(va[j].x, va[j].y), pack_bf16(va[j].z, va[j].w));
+                if (okb) *reinterpret_cast<uint2 *>(xs + rb * PITCH + kb) = make_uint2(pack_bf16(vb[j].x, vb[j].y), pack_bf16(vb[j].z, vb[j].w));
+            }
+        };
+        build(wave, wave + 4, true);
+        if (nb > 8) build(wave + 8, wave + 12, false);
+    }
+    stamp(1);
+    __syncthreads();
+    stamp(2);
+
+    // epilogue operands of the output this lane will finish (wave i < 4 finishes accumulator register i): requested now, used after the
+    // reduction - they land while the weight fragments are waited for
+    const int oi = wave & 3;
+    const int on = n0 + 4 * q + oi, ob = bt + r;
+    const bool out_ok = wave < 4 && 4 * q + oi < R && on < a.N && r < nb;
+    float e_bias = 0.f, e_res = 0.f, e_rw = 1.f, e_rb = 0.f, rmean = 0.f, rrstd = 1.f;
+    if (wave < 4) {
+        const int cn = out_ok ? on : 0, cb = out_ok ? ob : 0;
+        if (a.bias) e_bias = a.bias[cn];
+        if (a.residual) e_res = a.residual[(size_t)cb * a.ldr + cn];
+        if (a.rln_w) {
+            e_rw = a.rln_w[cn];
+            e_rb = a.rln_b[cn];
+            rmean = a.rstats[cb * 2];
+            rrstd = a.rstats[cb * 2 + 1];
+        }
+    }
+    // MFMA over this wave's K slice; batch columns >= nb read row 0 (their outputs are never stored)
+    const unsigned char *xfrag = xs + (r < nb ? r : 0) * PITCH + (wave * 256 + 8 * q) * 2;
+    uint4 xf[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) xf[c] = *reinterpret_cast<const uint4 *>(xfrag + 64 * c);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[c]), __builtin_bit_cast(bf16x8, xf[c]), acc, 0, 0, 0);
+    *reinterpret_cast<f32x4 *>(red + wave * 256 + lane * 4) = acc;
+    stamp(3);
+    __syncthreads();
+    stamp(4);
+    if (wave < 4) {
+        // D layout: col (batch) = lane & 15, row (weight row) = 4 * (lane >> 4) + register
+        float v = e_bias;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w * 256 + lane * 4 + oi];
+        const bool rnd = a.flags & ACAI_GEMM_ROUND_BF16;
+        if (rnd) v = round_bf16(v);
+        if (a.flags & ACAI_GEMM_GELU) {
+            v = gelu_erf(v);
+            if (rnd) v = round_bf16(v);
+        }
+        if (out_ok) {
+            if (a.k_cache && on >= a.E) {   // KVCache.update (K:94-95): position = entries already cached
+                const int kv = (on - a.E) / a.E, e = (on - a.E) - kv * a.E, hh = e / a.dh, dd = e - hh * a.dh;
+                const size_t off = (((size_t)ob * a.H + hh) * a.Tmax + a.step[1]) * a.dhp + dd;
+                reinterpret_cast<bf16_t *>(kv ? a.v_cache : a.k_cache)[off] = f2bf(v);
+            }
+            if (a.residual) v += a.rln_w ? (e_res - rmean) * rrstd * e_rw + e_rb : e_res;
+            if (a.y_bf16)
+                reinterpret_cast<bf16_t *>(a.y)[(size_t)ob * a.ldy + on] = f2bf(v);
+            else
+                a.y[(size_t)ob * a.ldy + on] = v;
+        }
+    }
+    stamp(5);
 }
 
 static inline bool skinny_mfma_ok(const SkinnyArgs &a) {
@@ -422,7 +629,29 @@ int launch_skinny(const SkinnyArgs &a, hipStream_t st) {
             static const int ntm = getenv("ACAI_SKINNY_NT") ? atoi(getenv("ACAI_SKINNY_NT")) : 1;
             if (ntm == 0 || (ntm == 2 && (size_t)a.N * a.K * 2 < (8u << 20))) b.w_cached = 1;
             b.rows_per_block = rpb ? rpb : (a.N >= 2560 ? 16 : (a.N >= 1600 ? 8 : 4));
+            b.stamps = nullptr;
+            if (g_stamps && g_stamp_next < g_stamp_cap) b.stamps = g_stamps + (size_t)(g_stamp_next++) * 1024 * 8;
             // (the K = 4096 form holds a 131 KB activation image: one workgroup per CU, so its batch tiles stay a loop inside the workgroup)
+            static const bool no_chain = getenv("ACAI_SKINNY_CHAIN") && atoi(getenv("ACAI_SKINNY_CHAIN")) == 0;   // A/B aid
+            const bool chain_ok = !no_chain && (size_t)a.N * a.ldw * 2 < 0xFFF00000u && (a.ldx % 8 == 0) && (!a.stats_out || a.ln_w);
+            if (chain_ok && ((a.K == 1024 && !a.x_bf16) || (a.K == 4096 && a.x_bf16 && !a.ln_w))) {
+                static bool attr2 = false;
+                if (!attr2) {
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_chain_kernel<true, false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+                    attr2 = true;
+                }
+                const dim3 cgrid(cdiv(a.N, b.rows_per_block), cdiv(a.B, 16));
+                const int nw = a.x_bf16 ? 16 : 4;
+                const size_t clds = (size_t)nw * 1024 + (size_t)rows * (a.K * 2 + 16);
+                if (a.x_bf16)
+                    hipLaunchKernelGGL((skinny_chain_kernel<true, false, 16>), cgrid, dim3(1024), clds, st, b);
+                else if (a.ln_w)
+                    hipLaunchKernelGGL((skinny_chain_kernel<false, true, 4>), cgrid, dim3(256), clds, st, b);
+                else
+                    hipLaunchKernelGGL((skinny_chain_kernel<false, false, 4>), cgrid, dim3(256), clds, st, b);
+                ACAI_LAUNCH_CHECK("skinny_chain");
+                return 0;
+            }
             const dim3 grid(cdiv(a.N, b.rows_per_block), wide ? 1 : cdiv(a.B, 16));
             if (wide)
                 hipLaunchKernelGGL((skinny_mfma_kernel<true, 1, 16>), grid, dim3(1024), lds, st, b);
@@ -1299,6 +1528,15 @@ extern "C" int acai_decode_attn(const float *q, int ldq, const void *kc, const v
     if (rc || !out) return rc;  // out == NULL: partials only (lets a benchmark time the streaming kernel alone)
     hipLaunchKernelGGL(attn_combine_kernel, dim3(H, B), dim3(64), 0, st, partial, out, ldo, H, dh, dhp, nsplit, round_out);
     ACAI_LAUNCH_CHECK("attn_combine");
+    return 0;
+}
+
+// Diagnostic: from now on every MFMA skinny launch (up to cap_launches, 1024 workgroups each) writes s_memrealtime stamps of its stages
+// into buf[launch][workgroup][8]; buf = NULL switches it off and rewinds the slot counter.  Not part of the product path.
+extern "C" int acai_debug_stamps(void *buf, int cap_launches) {
+    g_stamps = (unsigned long long *)buf;
+    g_stamp_cap = buf ? cap_launches : 0;
+    g_stamp_next = 0;
     return 0;
 }
 

@@ -92,6 +92,9 @@ int acai_gather_rows(const float *table, const int32_t *idx, const float *add, f
 int acai_pe_interp_fwd(const float *table, int Hin, int Win, int E, float *out, int Hout, int Wout, void *stream);
 int acai_pe_interp_bwd(const float *dout, int Hout, int Wout, int E, float *dtable, int Hin, int Win, void *stream);
 
+/* Diagnostic aid (tools/stamp_decode.py): s_memrealtime stamps of the decode GEMV kernel's stages, buf[launch][1024][8] uint64. */
+int acai_debug_stamps(void *buf, int cap_launches);
+
 /* autocast's fp32 -> bf16 input cast (round to nearest even) for an activation that feeds a bf16 GEMM. */
 int acai_cast_f32_bf16(const float *x, void *y, int64_t n, void *stream);
 
