@@ -81,12 +81,40 @@ struct TileLayout {
     __device__ static __forceinline__ int off(int row, int chunk) { return row * PITCH + ((chunk ^ swz(row)) << 4); }
 };
 
+// erf to fp32 accuracy (max |error| 6e-8 against double erf over [-6, 6], checked numerically: tools/check_erf.py), branch-free: both
+// polynomial pieces are evaluated and selected - 14 FMAs, one exp2, a select.  The device library's erff costs ~2.5x the MFMA time of a
+// K = 512 output tile when it sits in a GEMM epilogue (the GELU epilogue of linear1 ran at 378 TF against 635 TF for the same product
+// without it); this form is what every GELU of the path uses (forward, derivative, decode GEMV).
+__device__ __forceinline__ float acai_erff(float a) {
+    const float t = fabsf(a), s = a * a;
+    // |a| > 0.927734375: 1 - exp(p(t)), p of degree 7 in t
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    r = 1.0f - __builtin_amdgcn_exp2f(r * 1.4426950408889634f);
+    r = copysignf(r, a);
+    // |a| <= 0.927734375: a + a q(a^2)
+    float q = -5.96761703e-4f;
+    q = fmaf(q, s, 4.99119423e-3f);
+    q = fmaf(q, s, -2.67681349e-2f);
+    q = fmaf(q, s, 1.12819925e-1f);
+    q = fmaf(q, s, -3.76125336e-1f);
+    q = fmaf(q, s, 1.28379166e-1f);
+    q = fmaf(q, a, a);
+    return t > 0.927734375f ? r : q;
+}
+
 // exact-erf GELU, as torch's F.gelu(approximate="none")
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + acai_erff(x * 0.70710678118654752440f)); }
 
 // d/dx of the exact-erf GELU
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+    return 0.5f * (1.0f + acai_erff(x * 0.70710678118654752440f)) +
+           x * 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
 }
 
 template <typename T> struct DT;

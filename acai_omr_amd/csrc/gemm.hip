@@ -313,29 +313,11 @@ __device__ __forceinline__ void gemm_vec_epilogue(const GemmArgs &g, const f32x1
     // The bf16 rounding on the way into LDS is skipped when the value goes straight to a bf16 store, which rounds the same number the same way
     // (measured: no change in tile time -- the epilogue is a latency chain, not VALU issue).
     const bool pre_round = do_round && (do_gelu || g.aux_mode != 0 || g.residual != nullptr || g.out_dtype != ACAI_BF16);
-    auto finish = [&](f32x4 &v, int row, int col) {   // four consecutive columns of one row, after bias / rounding
+    // `a4`: the saved pre-activation of these four columns (aux_mode 2, loaded by the caller in one access per lane)
+    auto finish = [&](f32x4 &v, int row, int col, const float (&a4)[4]) {   // four consecutive columns of one row, after bias / rounding
         if (g.aux_mode == 2) {
-            float a4[4];
-            if (g.out_dtype == ACAI_BF16) {
-                const uint2 r = *reinterpret_cast<const uint2 *>(reinterpret_cast<const bf16_t *>(g.aux) + (size_t)row * g.ldaux + col);
-                a4[0] = __uint_as_float(r.x << 16); a4[1] = __uint_as_float(r.x & 0xFFFF0000u);
-                a4[2] = __uint_as_float(r.y << 16); a4[3] = __uint_as_float(r.y & 0xFFFF0000u);
-            } else {
-                const f32x4 r = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(g.aux) + (size_t)row * g.ldaux + col);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) a4[e] = r[e];
-            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(a4[e]);
-        }
-        if (g.aux_mode == 1) {
-            if (g.out_dtype == ACAI_BF16) {
-                uint2 o;
-                o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]);
-                *reinterpret_cast<uint2 *>(reinterpret_cast<bf16_t *>(g.aux) + (size_t)row * g.ldaux + col) = o;
-            } else {
-                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.aux) + (size_t)row * g.ldaux + col) = v;
-            }
         }
         if (do_gelu) {
 #pragma unroll
@@ -370,8 +352,21 @@ __device__ __forceinline__ void gemm_vec_epilogue(const GemmArgs &g, const f32x1
                 const int row = row_base + r;
                 if (row < g.M && c8 < n_valid) {
                     f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c8), v1 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c8 + 4);
-                    finish(v0, row, col_base + c8);
-                    finish(v1, row, col_base + c8 + 4);
+                    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+                    bf16_t *auxp = reinterpret_cast<bf16_t *>(g.aux) + (size_t)row * g.ldaux + col_base + c8;
+                    if (g.aux_mode == 2) {        // saved pre-activation: ONE 16-byte load per lane
+                        const uint4 r4 = *reinterpret_cast<const uint4 *>(auxp);
+                        a0[0] = __uint_as_float(r4.x << 16); a0[1] = __uint_as_float(r4.x & 0xFFFF0000u);
+                        a0[2] = __uint_as_float(r4.y << 16); a0[3] = __uint_as_float(r4.y & 0xFFFF0000u);
+                        a1[0] = __uint_as_float(r4.z << 16); a1[1] = __uint_as_float(r4.z & 0xFFFF0000u);
+                        a1[2] = __uint_as_float(r4.w << 16); a1[3] = __uint_as_float(r4.w & 0xFFFF0000u);
+                    } else if (g.aux_mode == 1) {  // keep the pre-activation: ONE 16-byte store per lane (was two 8-byte ones: the tail is store-issue bound)
+                        uint4 p4;
+                        p4.x = pack_bf16(v0[0], v0[1]); p4.y = pack_bf16(v0[2], v0[3]); p4.z = pack_bf16(v1[0], v1[1]); p4.w = pack_bf16(v1[2], v1[3]);
+                        *reinterpret_cast<uint4 *>(auxp) = p4;
+                    }
+                    finish(v0, row, col_base + c8, a0);
+                    finish(v1, row, col_base + c8 + 4, a1);
                     uint4 o;
                     o.x = pack_bf16(v0[0], v0[1]); o.y = pack_bf16(v0[2], v0[3]); o.z = pack_bf16(v1[0], v1[1]); o.w = pack_bf16(v1[2], v1[3]);
                     *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(g.C) + (size_t)row * ldc_e + col_base + c8) = o;
@@ -384,7 +379,16 @@ __device__ __forceinline__ void gemm_vec_epilogue(const GemmArgs &g, const f32x1
                 const int row = row_base + r;
                 if (row < g.M && c4 < n_valid) {
                     f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c4);
-                    finish(v0, row, col_base + c4);
+                    float a0[4] = {0.f, 0.f, 0.f, 0.f};
+                    float *auxp = reinterpret_cast<float *>(g.aux) + (size_t)row * g.ldaux + col_base + c4;
+                    if (g.aux_mode == 2) {
+                        const f32x4 r4 = *reinterpret_cast<const f32x4 *>(auxp);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a0[e] = r4[e];
+                    } else if (g.aux_mode == 1) {
+                        *reinterpret_cast<f32x4 *>(auxp) = v0;
+                    }
+                    finish(v0, row, col_base + c4, a0);
                     *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)row * ldc_e + col_base + c4) = v0;
                 }
             }

