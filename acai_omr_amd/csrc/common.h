@@ -129,6 +129,22 @@ template <> struct DT<bf16_t> {
     __device__ static __forceinline__ void st(bf16_t *p, float v) { *p = f2bf(v); }
 };
 
+// Wave-wide sum on the DPP network (no LDS crossbar): quad swaps, half-row and row mirrors give every lane its 16-lane row's sum, two
+// row broadcasts carry it across the four rows into lane 63, one v_readlane hands it to every lane through an SGPR.  7 dependent VALU
+// steps of a few cycles each instead of 6 ds_bpermute round trips (~100 cycles each) - the LayerNorm-on-load of the decode GEMVs sits
+// on the step's critical path 37 times per token.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define ACAI_DPP_ADD(CTRL, ROWMASK) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false))
+    ACAI_DPP_ADD(0xB1, 0xF);    // quad_perm [1,0,3,2]
+    ACAI_DPP_ADD(0x4E, 0xF);    // quad_perm [2,3,0,1]
+    ACAI_DPP_ADD(0x141, 0xF);   // row_half_mirror
+    ACAI_DPP_ADD(0x140, 0xF);   // row_mirror: every lane now holds its row's sum
+    ACAI_DPP_ADD(0x142, 0xA);   // row_bcast15 into rows 1 and 3
+    ACAI_DPP_ADD(0x143, 0xC);   // row_bcast31 into rows 2 and 3: lane 63 holds the wave's sum
+#undef ACAI_DPP_ADD
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

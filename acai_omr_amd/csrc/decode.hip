@@ -501,13 +501,10 @@ __global__ __launch_bounds__(64 * NW) void skinny_chain_kernel(SkinnyArgs a) {
                     t1 += (vb[j].x + vb[j].y) + (vb[j].z + vb[j].w);
                     u1 += (vb[j].x * vb[j].x + vb[j].y * vb[j].y) + (vb[j].z * vb[j].z + vb[j].w * vb[j].w);
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    t0 += __shfl_xor(t0, o);
-                    u0 += __shfl_xor(u0, o);
-                    t1 += __shfl_xor(t1, o);
-                    u1 += __shfl_xor(u1, o);
-                }
+                t0 = wave_sum_dpp(t0);   // four independent chains on the DPP network
+                u0 = wave_sum_dpp(u0);
+                t1 = wave_sum_dpp(t1);
+                u1 = wave_sum_dpp(u1);
                 const float invK = 1.0f / (float)K;
                 const float m0 = t0 * invK, m1 = t1 * invK;
                 const float s0 = 1.0f / sqrtf(fmaxf(u0 * invK - m0 * m0, 0.f) + a.ln_eps), s1 = 1.0f / sqrtf(fmaxf(u1 * invK - m1 * m1, 0.f) + a.ln_eps);
@@ -695,9 +692,9 @@ struct DAttnArgs {
 // LPK = lanes per key = dhp * sizeof(TC) / 16.  RAGGED = cross attention over the ragged encoder memory (the dominant
 // HBM stream of a decode step); !RAGGED = self attention over the [B][H][Tmax][dhp] cache.  Two instantiations so that
 // rocprof reports them as separate kernels.
-template <typename TC, int LPK, bool RAGGED>
+template <typename TC, int LPK, bool RAGGED, int U = 2>
 __global__ __launch_bounds__(256) void decode_attn_kernel(DAttnArgs a) {
-    constexpr int EPC = 16 / sizeof(TC), KPW = 64 / LPK, U = 2;
+    constexpr int EPC = 16 / sizeof(TC), KPW = 64 / LPK;
     __shared__ float red[4][2 + 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = lane % LPK, kg = lane / LPK;
@@ -1306,10 +1303,13 @@ inline int launch_dattn_group(const DAttnArgs &a, int B, int group, hipStream_t 
 template <typename TC>
 int launch_dattn(const DAttnArgs &a, int B, hipStream_t st) {
     const int lpk = a.dhp * (int)sizeof(TC) / 16;
+    static const int dattn_u = getenv("ACAI_DATTN_U") ? atoi(getenv("ACAI_DATTN_U")) : 2;   // key groups in flight per lane (A/B aid)
     dim3 grid(a.nsplit, a.H, B);
 #define ACAI_DA(L)                                                                                        \
     case L:                                                                                               \
-        if (a.seq_off) hipLaunchKernelGGL((decode_attn_kernel<TC, L, true>), grid, dim3(256), 0, st, a);  \
+        if (a.seq_off && L == 8 && dattn_u == 4) hipLaunchKernelGGL((decode_attn_kernel<TC, 8, true, 4>), grid, dim3(256), 0, st, a);  \
+        else if (a.seq_off && L == 8 && dattn_u == 3) hipLaunchKernelGGL((decode_attn_kernel<TC, 8, true, 3>), grid, dim3(256), 0, st, a);  \
+        else if (a.seq_off) hipLaunchKernelGGL((decode_attn_kernel<TC, L, true>), grid, dim3(256), 0, st, a);  \
         else hipLaunchKernelGGL((decode_attn_kernel<TC, L, false>), grid, dim3(256), 0, st, a);           \
         break;
     switch (lpk) {
