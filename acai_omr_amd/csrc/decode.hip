@@ -42,6 +42,8 @@ struct SkinnyArgs {
     int x_bf16, y_bf16;      // activation in / out stored as bf16 (x: row stride ldx in bf16 elements)
     int rows_per_block;      // MFMA kernel: weight rows per workgroup (set by the launcher)
     int w_cached;            // non-zero: default-policy (cacheable) weight loads instead of non-temporal ones (ACAI_SKINNY_NT, an A/B aid)
+    const float *ln2_w, *ln2_b;   // chain kernel only: a SECOND LayerNorm applied to the normalised row (last layer's norm3, then the stack's final norm)
+    float ln2_eps;
     unsigned long long *stamps;   // diagnostic (acai_debug_stamps): [workgroup][8] s_memrealtime stamps (100 MHz) of the kernel's stages, else null
 };
 
@@ -418,14 +420,16 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
 //   * one wave reduced and finished all 4 x 64 outputs: here wave i finishes accumulator register i of every lane (4 waves in parallel).
 typedef __attribute__((vector_size(16))) unsigned int skm_v4u;
 
-template <bool XBF16, bool HAS_LN, int NW>
+template <bool XBF16, int LN, int NW>   // LN: 0 = none, 1 = LayerNorm on load, 2 = two LayerNorms in a row (unembed: norm3 of the last layer, then the final norm)
 __global__ __launch_bounds__(64 * NW) void skinny_chain_kernel(SkinnyArgs a) {
+    constexpr bool HAS_LN = LN > 0;
     constexpr int K = 256 * NW, PITCH = K * 2 + 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     asm volatile("" ::"s"(a.x), "s"(a.W), "s"(a.bias), "s"(a.residual), "s"(a.y), "s"(a.ldx), "s"(a.ldw), "s"(a.ldr), "s"(a.ldy), "s"(a.B), "s"(a.N),
                  "s"(a.flags), "s"(a.k_cache), "s"(a.v_cache), "s"(a.step));
     asm volatile("" ::"s"(a.E), "s"(a.H), "s"(a.dh), "s"(a.dhp), "s"(a.Tmax), "s"(a.ln_w), "s"(a.ln_b), "s"(a.ln_eps), "s"(a.stats_out), "s"(a.rln_w),
                  "s"(a.rln_b), "s"(a.rstats), "s"(a.y_bf16), "s"(a.rows_per_block), "s"(a.stamps));
+    if constexpr (LN == 2) asm volatile("" ::"s"(a.ln2_w), "s"(a.ln2_b), "s"(a.ln2_eps));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_chain_kernel(SkinnyArgs a) {
         auto build = [&](int ra, int rb, bool first) {
             const bool oka = ra < nb, okb = rb < nb;
             const float *pa = a.x + (size_t)(bt + (oka ? ra : 0)) * a.ldx + lane * 4, *pb = a.x + (size_t)(bt + (okb ? rb : 0)) * a.ldx + lane * 4;
-            float4 va[4], vb[4], lw[4], lb[4];
+            float4 va[4], vb[4], lw[4], lb[4], lw2[4], lb2[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 va[j] = *reinterpret_cast<const float4 *>(pa + j * 256);
@@ -487,6 +491,13 @@ __global__ __launch_bounds__(64 * NW) void skinny_chain_kernel(SkinnyArgs a) {
                 for (int j = 0; j < 4; ++j) {
                     lw[j] = *reinterpret_cast<const float4 *>(a.ln_w + j * 256 + lane * 4);
                     lb[j] = *reinterpret_cast<const float4 *>(a.ln_b + j * 256 + lane * 4);
+                }
+            }
+            if constexpr (LN == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    lw2[j] = *reinterpret_cast<const float4 *>(a.ln2_w + j * 256 + lane * 4);
+                    lb2[j] = *reinterpret_cast<const float4 *>(a.ln2_b + j * 256 + lane * 4);
                 }
             }
             if (first) request_weights();   // behind this wave's activation rows: loads return in issue order
@@ -524,6 +535,32 @@ __global__ __launch_bounds__(64 * NW) void skinny_chain_kernel(SkinnyArgs a) {
                     va[j].z = (va[j].z - m0) * s0 * lw[j].z + lb[j].z; va[j].w = (va[j].w - m0) * s0 * lw[j].w + lb[j].w;
                     vb[j].x = (vb[j].x - m1) * s1 * lw[j].x + lb[j].x; vb[j].y = (vb[j].y - m1) * s1 * lw[j].y + lb[j].y;
                     vb[j].z = (vb[j].z - m1) * s1 * lw[j].z + lb[j].z; vb[j].w = (vb[j].w - m1) * s1 * lw[j].w + lb[j].w;
+                }
+            }
+            if constexpr (LN == 2) {   // the second norm on the fp32 rows in registers (two-pass variance: the rows are O(1) after the first)
+                float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    t0 += (va[j].x + va[j].y) + (va[j].z + va[j].w);
+                    t1 += (vb[j].x + vb[j].y) + (vb[j].z + vb[j].w);
+                }
+                const float invK = 1.0f / (float)K;
+                const float m0 = wave_sum_dpp(t0) * invK, m1 = wave_sum_dpp(t1) * invK;
+                float u0 = 0.f, u1 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    va[j].x -= m0; va[j].y -= m0; va[j].z -= m0; va[j].w -= m0;
+                    vb[j].x -= m1; vb[j].y -= m1; vb[j].z -= m1; vb[j].w -= m1;
+                    u0 += (va[j].x * va[j].x + va[j].y * va[j].y) + (va[j].z * va[j].z + va[j].w * va[j].w);
+                    u1 += (vb[j].x * vb[j].x + vb[j].y * vb[j].y) + (vb[j].z * vb[j].z + vb[j].w * vb[j].w);
+                }
+                const float s0 = 1.0f / sqrtf(wave_sum_dpp(u0) * invK + a.ln2_eps), s1 = 1.0f / sqrtf(wave_sum_dpp(u1) * invK + a.ln2_eps);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    va[j].x = va[j].x * s0 * lw2[j].x + lb2[j].x; va[j].y = va[j].y * s0 * lw2[j].y + lb2[j].y;
+                    va[j].z = va[j].z * s0 * lw2[j].z + lb2[j].z; va[j].w = va[j].w * s0 * lw2[j].w + lb2[j].w;
+                    vb[j].x = vb[j].x * s1 * lw2[j].x + lb2[j].x; vb[j].y = vb[j].y * s1 * lw2[j].y + lb2[j].y;
+                    vb[j].z = vb[j].z * s1 * lw2[j].z + lb2[j].z; vb[j].w = vb[j].w * s1 * lw2[j].w + lb2[j].w;
                 }
             }
 #pragma unroll
@@ -630,22 +667,25 @@ int launch_skinny(const SkinnyArgs &a, hipStream_t st) {
             if (g_stamps && g_stamp_next < g_stamp_cap) b.stamps = g_stamps + (size_t)(g_stamp_next++) * 1024 * 8;
             // (the K = 4096 form holds a 131 KB activation image: one workgroup per CU, so its batch tiles stay a loop inside the workgroup)
             static const bool no_chain = getenv("ACAI_SKINNY_CHAIN") && atoi(getenv("ACAI_SKINNY_CHAIN")) == 0;   // A/B aid
-            const bool chain_ok = !no_chain && (size_t)a.N * a.ldw * 2 < 0xFFF00000u && (a.ldx % 8 == 0) && (!a.stats_out || a.ln_w);
+            const bool chain_ok = !no_chain && (size_t)a.N * a.ldw * 2 < 0xFFF00000u && (a.ldx % 8 == 0);   // (row statistics are only published with a LayerNorm on load, as in skinny_mfma_kernel)
+            if (a.ln2_w && !(chain_ok && a.K == 1024 && !a.x_bf16 && a.ln_w)) return acai_set_err(-1, "skinny_gemm: the double LayerNorm needs the chain kernel (K = 1024, fp32 activations)");
             if (chain_ok && ((a.K == 1024 && !a.x_bf16) || (a.K == 4096 && a.x_bf16 && !a.ln_w))) {
                 static bool attr2 = false;
                 if (!attr2) {
-                    hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_chain_kernel<true, false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_chain_kernel<true, 0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
                     attr2 = true;
                 }
                 const dim3 cgrid(cdiv(a.N, b.rows_per_block), cdiv(a.B, 16));
                 const int nw = a.x_bf16 ? 16 : 4;
                 const size_t clds = (size_t)nw * 1024 + (size_t)rows * (a.K * 2 + 16);
                 if (a.x_bf16)
-                    hipLaunchKernelGGL((skinny_chain_kernel<true, false, 16>), cgrid, dim3(1024), clds, st, b);
+                    hipLaunchKernelGGL((skinny_chain_kernel<true, 0, 16>), cgrid, dim3(1024), clds, st, b);
+                else if (a.ln_w && a.ln2_w)
+                    hipLaunchKernelGGL((skinny_chain_kernel<false, 2, 4>), cgrid, dim3(256), clds, st, b);
                 else if (a.ln_w)
-                    hipLaunchKernelGGL((skinny_chain_kernel<false, true, 4>), cgrid, dim3(256), clds, st, b);
+                    hipLaunchKernelGGL((skinny_chain_kernel<false, 1, 4>), cgrid, dim3(256), clds, st, b);
                 else
-                    hipLaunchKernelGGL((skinny_chain_kernel<false, false, 4>), cgrid, dim3(256), clds, st, b);
+                    hipLaunchKernelGGL((skinny_chain_kernel<false, 0, 4>), cgrid, dim3(256), clds, st, b);
                 ACAI_LAUNCH_CHECK("skinny_chain");
                 return 0;
             }
@@ -1427,7 +1467,17 @@ int decode_core(const AcaiDecoder *d, const int64_t *tokens, hipStream_t st, boo
             lnw = ly->n3_w;
             lnb = ly->n3_b;
         }
-        // x = norm3(z3) of the last layer, then the stack's final norm (eps 1e-6) fused into the unembed GEMV
+        // x = norm3(z3) of the last layer, then the stack's final norm (eps 1e-6): both fused into the unembed GEMV's load when the chain
+        // kernel takes it (E = 1024) - no stand-alone LayerNorm launch is left in a token step
+        static const bool no_chain2 = getenv("ACAI_SKINNY_CHAIN") && atoi(getenv("ACAI_SKINNY_CHAIN")) == 0;
+        if (do_unembed && d->fn_w && E == 1024 && !no_chain2 && lnw) {
+            SkinnyArgs s{};
+            s.x = zin; s.W = d->unembed_w; s.bias = d->unembed_b; s.y = d->logits;
+            s.ldx = E; s.ldw = E; s.ldy = d->V; s.B = B; s.N = d->V; s.K = E; s.flags = rnd;
+            s.ln_w = lnw; s.ln_b = lnb; s.ln_eps = 1e-5f;
+            s.ln2_w = d->fn_w; s.ln2_b = d->fn_b; s.ln2_eps = 1e-6f;
+            return launch_skinny<TW>(s, st);
+        }
         if ((rc = acai_layernorm_fwd(zin, lnw, lnb, 1e-5f, d->proj, nullptr, B, E, st))) return rc;
         if (do_unembed && d->fn_w) {
             SkinnyArgs s{};
