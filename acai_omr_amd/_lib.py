@@ -81,6 +81,7 @@ _SIGNATURES = {
                                     c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "acai_decode_attn": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                  c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "acai_decode_embed": (c_int, [POINTER(AcaiDecoder), c_void_p]),
     "acai_decode_step": (c_int, [POINTER(AcaiDecoder), c_void_p]),
     "acai_decode_sample_step": (c_int, [POINTER(AcaiDecoder), c_void_p, c_int, c_float, c_void_p]),
     "acai_decode_logits": (c_int, [POINTER(AcaiDecoder), c_void_p, c_int, c_void_p]),

@@ -1186,9 +1186,11 @@ __global__ __launch_bounds__(256) void embed_kernel(const float *emb, const floa
 __global__ void set_step_kernel(int32_t *step, int t) { step[0] = t; }
 
 // cached_get_next_token (M:579-581) + loop bookkeeping (M:606-611).  One workgroup, wave w takes rows w, w+4, ...
+// With `emb`: the wave that chose row b's token also writes the NEXT step's input x[b] = vocab_embedding[token] + pos_embedding[t + 1]
+// (quirk Q1: the token at index t is embedded with position t + 1, M:576), so a token step needs no embed launch of its own.
 __global__ __launch_bounds__(1024) void argmax_logprob_kernel(const float *logits, int V, int B, int64_t *seqs, float *logprobs,
                                                              int max_len, int32_t *step, int32_t *finished, int eos, int round_lp,
-                                                             int bookkeeping) {
+                                                             int bookkeeping, const float *emb, const float *pos, float *x, int E, int Tmax) {
     __shared__ int unfinished[16];   // up to 16 waves: one row per wave for the usual batch sizes (the rows of a wave run back to back)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = step[0];
@@ -1228,6 +1230,11 @@ __global__ __launch_bounds__(1024) void argmax_logprob_kernel(const float *logit
                 finished[b] = fin;
             }
             cnt += fin ? 0 : 1;
+            if (emb && t + 1 < Tmax)
+                for (int i = lane * 4; i < E; i += 256) {
+                    const float4 ev = *reinterpret_cast<const float4 *>(emb + (size_t)bi * E + i), pv = *reinterpret_cast<const float4 *>(pos + (size_t)(t + 1) * E + i);
+                    *reinterpret_cast<float4 *>(x + (size_t)b * E + i) = make_float4(ev.x + pv.x, ev.y + pv.y, ev.z + pv.z, ev.w + pv.w);
+                }
         } else if (lane == 0) {
             seqs[b] = bi;
             logprobs[b] = lp;
@@ -1251,7 +1258,8 @@ __global__ __launch_bounds__(1024) void argmax_logprob_kernel(const float *logit
 // (logits, u) that the oracle restates.  One wave per row: k rounds of a wave-wide arg-max build the sorted top-k (k <= 64).
 __global__ __launch_bounds__(256) void sample_logprob_kernel(const float *logits, int V, int B, int64_t *seqs, float *logprobs, int max_len,
                                                              const int32_t *step, int32_t *finished, int eos, int round_lp,
-                                                             const float *uniforms, int top_k, float inv_temperature) {
+                                                             const float *uniforms, int top_k, float inv_temperature, const float *emb,
+                                                             const float *pos, float *xnext, int E, int Tmax) {
     __shared__ float sv[4][64];
     __shared__ int si[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1316,6 +1324,11 @@ __global__ __launch_bounds__(256) void sample_logprob_kernel(const float *logits
         logprobs[(size_t)b * max_len + t] = lp;
         if (tok == eos) finished[b] = 1;
     }
+    if (emb && t + 1 < Tmax)   // next step's input (see argmax_logprob_kernel)
+        for (int i = lane * 4; i < E; i += 256) {
+            const float4 ev = *reinterpret_cast<const float4 *>(emb + (size_t)tok * E + i), pv = *reinterpret_cast<const float4 *>(pos + (size_t)(t + 1) * E + i);
+            *reinterpret_cast<float4 *>(xnext + (size_t)b * E + i) = make_float4(ev.x + pv.x, ev.y + pv.y, ev.z + pv.z, ev.w + pv.w);
+        }
 }
 
 // loop bookkeeping after a sampling step: unfinished count, advance position and cache length
@@ -1604,16 +1617,30 @@ extern "C" int acai_decode_hidden(const AcaiDecoder *d, const float *x_in, void 
     return 0;
 }
 
+// x = vocab_embedding[seqs[:, t-1]] + pos_embedding[t] for the armed state (t = step[0]): run once after arming; every later step's input is
+// written by the previous step's argmax / sampling kernel.
+extern "C" int acai_decode_embed(const AcaiDecoder *d, void *stream) {
+    int rc = check_decoder(d);
+    if (rc) return rc;
+    ACAI_CHECK_ARG(d->emb && d->pos && d->seqs && d->max_len > 1, "acai_decode_embed: decoder has no embedding / sequence state");
+    hipLaunchKernelGGL(embed_kernel, dim3(d->B), dim3(256), 0, (hipStream_t)stream, (const float *)d->emb, (const float *)d->pos, (const int64_t *)nullptr,
+                       (const int64_t *)d->seqs, (const int32_t *)d->step, d->max_len, d->x, d->E);
+    ACAI_LAUNCH_CHECK("embed");
+    return 0;
+}
+
 extern "C" int acai_decode_step(const AcaiDecoder *d, void *stream) {
     int rc = check_decoder(d);
     if (rc) return rc;
     ACAI_CHECK_ARG(d->emb && d->pos && d->unembed_w && d->logits, "acai_decode_step: decoder has no embedding / unembed");
     ACAI_CHECK_ARG(d->seqs && d->logprobs && d->finished && d->max_len > 1, "acai_decode_step: null sequence state");
     hipStream_t st = (hipStream_t)stream;
-    rc = d->dtype == ACAI_BF16 ? decode_core<bf16_t>(d, nullptr, st) : decode_core<float>(d, nullptr, st);
+    // the step's input x was written by the previous step's argmax (or by acai_decode_embed after arming) when E allows 16-byte rows
+    const bool chained = (d->E % 4 == 0);
+    rc = d->dtype == ACAI_BF16 ? decode_core<bf16_t>(d, nullptr, st, !chained) : decode_core<float>(d, nullptr, st, !chained);
     if (rc) return rc;
     hipLaunchKernelGGL(argmax_logprob_kernel, dim3(1), dim3(d->B > 8 ? 1024 : (d->B > 4 ? 512 : 256)), 0, st, d->logits, d->V, d->B, d->seqs, d->logprobs, d->max_len, d->step,
-                       d->finished, d->eos, (d->flags & ACAI_GEMM_ROUND_BF16) ? 1 : 0, 1);
+                       d->finished, d->eos, (d->flags & ACAI_GEMM_ROUND_BF16) ? 1 : 0, 1, chained ? (const float *)d->emb : nullptr, (const float *)d->pos, d->x, d->E, d->Tmax);
     ACAI_LAUNCH_CHECK("argmax_logprob");
     return 0;
 }
@@ -1626,10 +1653,12 @@ extern "C" int acai_decode_sample_step(const AcaiDecoder *d, const float *unifor
     ACAI_CHECK_ARG(uniforms && top_k >= 1 && top_k <= 64 && temperature > 0.f && d->V <= 512,
                    "acai_decode_sample_step: needs uniforms, 1 <= top_k <= 64, temperature > 0, vocabulary <= 512 (top_k=%d V=%d)", top_k, d->V);
     hipStream_t st = (hipStream_t)stream;
-    rc = d->dtype == ACAI_BF16 ? decode_core<bf16_t>(d, nullptr, st) : decode_core<float>(d, nullptr, st);
+    const bool chained = (d->E % 4 == 0);
+    rc = d->dtype == ACAI_BF16 ? decode_core<bf16_t>(d, nullptr, st, !chained) : decode_core<float>(d, nullptr, st, !chained);
     if (rc) return rc;
     hipLaunchKernelGGL(sample_logprob_kernel, dim3(cdiv(d->B, 4)), dim3(256), 0, st, d->logits, d->V, d->B, d->seqs, d->logprobs, d->max_len, d->step,
-                       d->finished, d->eos, (d->flags & ACAI_GEMM_ROUND_BF16) ? 1 : 0, uniforms, top_k, 1.0f / temperature);
+                       d->finished, d->eos, (d->flags & ACAI_GEMM_ROUND_BF16) ? 1 : 0, uniforms, top_k, 1.0f / temperature,
+                       chained ? (const float *)d->emb : nullptr, (const float *)d->pos, d->x, d->E, d->Tmax);
     hipLaunchKernelGGL(sample_bookkeeping_kernel, dim3(1), dim3(64), 0, st, d->B, d->step, d->finished);
     ACAI_LAUNCH_CHECK("sample_logprob");
     return 0;

@@ -393,6 +393,8 @@ class DecodeEngine:
         self.finished.zero_()
         self.reset_self_cache()
         self.step.copy_(torch.tensor([1, 0], dtype=torch.int32))
+        # input of the first step (<bos> at position 1, quirk Q1); each step's argmax / sampling kernel writes the next step's input
+        _lib.check(_lib.lib().acai_decode_embed(ctypes.byref(self._desc), ops._st()), "acai_decode_embed")
 
     STEPS_PER_GRAPH = 8   # a graph replay costs ~10-15 us of launch latency: amortise it over several decode steps
 

@@ -201,6 +201,9 @@ typedef struct {
     float *stats;                       /* 6*B floats: published LayerNorm (mean, rstd) rows; NULL disables the fused-LN path */
 } AcaiDecoder;
 
+/* Input of the FIRST step after the device-side loop state was armed: x = vocab_embedding[seqs[:, t-1]] + pos_embedding[t], t = step[0]
+ * (M:521-524 with quirk Q1).  Every later step's input is written by the previous step's argmax / sampling kernel. */
+int acai_decode_embed(const AcaiDecoder *dec, void *stream);
 /* One greedy step t = *step for all B rows: embed seqs[:,t-1] with pos_embedding[t] (quirk Q1, M:576),
  * 12x cached_forward, final norm, unembed, argmax + log_softmax gather, seqs[:,t] / logprobs[:,t] update,
  * finished flags, ++*step.  Enqueues only kernels: capture it in a hipGraph and replay. */
