@@ -107,6 +107,32 @@ def gemm_nt(a, w, bias=None, residual=None, out_dtype=torch.float32, gelu=False,
     return out
 
 
+class _ZeroArena:
+    """Zeroed fp32 scratch for the split-K weight-gradient GEMMs (they accumulate with float atomics into a zeroed output): slices of a few
+    large chunks, each zeroed by ONE fill, instead of one `torch.zeros` launch per weight gradient (the MAE step issued ~380 five-microsecond
+    fills, the teacher-forced step ~700).  A slice becomes `param.grad` (autograd keeps the tensor it is handed), so a chunk lives exactly as
+    long as the gradients cut from it; a fresh chunk is taken from torch's caching allocator when the current one is used up."""
+    CHUNK = 64 << 20   # elements (256 MB)
+
+    def __init__(self):
+        self._buf, self._off = {}, {}
+
+    def take(self, rows, cols, device):
+        n = rows * cols
+        if n >= self.CHUNK // 4:
+            return torch.zeros(rows, cols, dtype=torch.float32, device=device)
+        key = (device.type, device.index)
+        buf, off = self._buf.get(key), self._off.get(key, 0)
+        if buf is None or off + n > buf.numel():
+            buf, off = torch.zeros(self.CHUNK, dtype=torch.float32, device=device), 0
+            self._buf[key] = buf
+        self._off[key] = off + ((n + 63) & ~63)   # 256-byte aligned slices
+        return buf[off:off + n].view(rows, cols)
+
+
+_ZEROS = _ZeroArena()
+
+
 def gemm(a, w, trans_a=False, trans_w=False, bias=None, residual=None, out_dtype=torch.float32, out=None):
     """out[M,N] = op(a) @ op(w)^T: logical a [M,K] (stored [K,M] if trans_a), logical w [N,K] (stored [K,N] if trans_w)."""
     _chk(a, "a"), _chk(w, "w")
@@ -116,7 +142,7 @@ def gemm(a, w, trans_a=False, trans_w=False, bias=None, residual=None, out_dtype
     assert K == K2, (a.shape, w.shape, trans_a, trans_w)
     if out is None:
         # the weight-gradient form accumulates (split-K atomics) into an fp32 output
-        out = torch.zeros(M, N, dtype=torch.float32, device=a.device) if (trans_a and trans_w) else torch.empty(M, N, dtype=out_dtype, device=a.device)
+        out = _ZEROS.take(M, N, a.device) if (trans_a and trans_w) else torch.empty(M, N, dtype=out_dtype, device=a.device)
     assert out.shape == (M, N) and out.stride(1) == 1
     if residual is not None:
         assert residual.dtype == torch.float32 and residual.shape == (M, N) and residual.stride(1) == 1

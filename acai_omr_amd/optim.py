@@ -62,8 +62,8 @@ class FusedAdamW(torch.optim.Optimizer):
     def _build(self, active, dev, steps):
         """Tensor table (pointers + per-tensor bias corrections: torch keeps `step` per parameter, so a parameter that skipped steps - frozen
         for a while, no gradient - carries its own count) and the chunk table.  The chunk table is rebuilt only when the pointers change; the
-        tensor table is re-uploaded every step (its bias corrections move)."""
-        key = tuple((gi, p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()) for gi, p, st in active)
+        tensor table is re-uploaded every step (its bias corrections move, and gradient pointers may: ops._ZeroArena)."""
+        key = tuple((gi, p.numel()) for gi, p, st in active)   # the chunk table depends on the tensor sizes only; pointers travel in the tensor table
         arr = (_lib.AcaiAdamWTensor * len(active))()
         for i, (gi, p, st) in enumerate(active):
             arr[i].p, arr[i].g, arr[i].m, arr[i].v = p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()

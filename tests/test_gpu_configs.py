@@ -563,3 +563,40 @@ def test_data_parallel_step_on_the_hip_path_two_ranks(dev):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["world"] == 2 and out["dp_parity_max_abs_diff"] < 1e-4, out
+
+
+def test_benchmarked_decode_shape_bf16_vs_oracle(dev):
+    """The BENCHMARKED configuration itself (BASELINE north star: batch 8, 4096-patch memories, full-size decoder, bf16 plumbing, hipGraph
+    replay - what `bench.py` times): greedy ids and log-probs of two of the eight rows against the CPU oracle's autocast restatement run on
+    that row alone; a differing token is tolerated only where the oracle's own top-2 margin is within bf16 resolution."""
+    from acai_omr_amd.models.models import OMRDecoder, ViTOMR
+    from oracle import vitomr_oracle as O
+    _threads()
+    torch.manual_seed(31)
+    dec = OMRDecoder(64, VOCAB, num_layers=12)
+    with torch.no_grad():
+        for n, p in dec.named_parameters():
+            if "norm" in n:
+                p.add_(0.1 * torch.randn_like(p))
+        dec.unembed.weight.mul_(6.0)
+        dec.unembed.bias[2] = -1.0e4
+    cached = dec.to_cached_version(8, torch.bfloat16)
+    cached.load_state_dict(dec.state_dict())
+    model = ViTOMR(None, None, cached.to(dev).eval())
+    S, steps = 4096, 33
+    mem = O.rbf16(torch.randn(8 * S, 1024, generator=torch.Generator().manual_seed(32)))
+    with torch.no_grad():
+        seqs, lps, mask = model._greedy_packed(None, mem.to(dev).to(torch.bfloat16), [S] * 8, steps)
+    assert seqs.shape == (8, steps)
+    sd = {"decoder." + k: v for k, v in dec.state_dict().items()}
+    for b in (1, 6):
+        oseqs, olps, omask, ologits = O.greedy_generate(mem[b * S:(b + 1) * S], [S], sd, 16, "bf16", steps, return_logits=True)
+        same = seqs[b].cpu() == oseqs[0]
+        top2 = ologits[0].topk(2, dim=-1).values
+        margin = top2[:, 0] - top2[:, 1]
+        bad = (~same).nonzero()
+        first = int(bad[0]) if len(bad) else steps
+        if len(bad):
+            assert float(margin[first - 1]) <= 0.13, (b, first, float(margin[first - 1]))
+        assert first >= 8, (b, first)
+        assert md(lps[b, 1:first], olps[0, 1:first]) < 0.07
