@@ -63,7 +63,7 @@ _SIGNATURES = {
                                      c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_int, c_int, c_float, c_uint32, c_void_p]),
     "acai_dropout_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_uint32, c_int, c_int, c_void_p]),
-    "acai_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "acai_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "acai_gelu_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "acai_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "acai_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),

@@ -71,17 +71,19 @@ __global__ __launch_bounds__(256) void ln_bwd_param_kernel(const float *__restri
 // per-lane partial dw / db over all rows of its chunk; the four waves' partials meet in LDS and leave as one atomic per column and workgroup.
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ dy, float eps,
-                                                           float *__restrict__ dx, bf16_t *__restrict__ dx_bf16, float *dw, float *db, int rows,
-                                                           int rows_per_block) {
+                                                           float *__restrict__ dx, bf16_t *__restrict__ dx_bf16, float *dw, float *db, float *dxsum,
+                                                           int rows, int rows_per_block) {
+    // dxsum (optional): column sums of dx as the consuming Linear sees it (the bf16 copy when one is written) = that Linear's bias gradient,
+    // formed here while dx is in registers instead of by a colsum launch that reads dx back from HBM
     constexpr int DIM = NV * 256;
     __shared__ float red[4][DIM];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-    f32x4 wv[NV], aw[NV], ab[NV];
+    f32x4 wv[NV], aw[NV], ab[NV], ac[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         wv[j] = *reinterpret_cast<const f32x4 *>(w + j * 256 + lane * 4);
-        aw[j] = ab[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        aw[j] = ab[j] = ac[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const float inv_dim = 1.0f / (float)DIM;
     for (int r = r0 + wave; r < r1; r += 4) {
@@ -129,16 +131,21 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float *__restri
                 pk.x = pack_bf16(o[0], o[1]);
                 pk.y = pack_bf16(o[2], o[3]);
                 *reinterpret_cast<uint2 *>(dx_bf16 + (size_t)r * DIM + j * 256 + lane * 4) = pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ac[j][e] += round_bf16(o[e]);
+            } else {
+                ac[j] += o;
             }
         }
     }
-    if (!dw) return;  // uniform
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < 3; ++pass) {
+        float *dst = pass == 0 ? dw : (pass == 1 ? db : dxsum);
+        if (!dst) continue;  // uniform
 #pragma unroll
-        for (int j = 0; j < NV; ++j) *reinterpret_cast<f32x4 *>(&red[wave][j * 256 + lane * 4]) = pass ? ab[j] : aw[j];
+        for (int j = 0; j < NV; ++j) *reinterpret_cast<f32x4 *>(&red[wave][j * 256 + lane * 4]) = pass == 0 ? aw[j] : (pass == 1 ? ab[j] : ac[j]);
         __syncthreads();
-        for (int c = threadIdx.x; c < DIM; c += 256) atomicAdd((pass ? db : dw) + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+        for (int c = threadIdx.x; c < DIM; c += 256) atomicAdd(dst + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
         __syncthreads();
     }
 }
@@ -350,7 +357,7 @@ static inline int grid1d(long n) {
 }  // namespace
 
 extern "C" int acai_layernorm_bwd(const float *x, const float *w, const float *dy, float eps, float *dx, void *dx_bf16, float *dw, float *db,
-                                  float *stats, int rows, int dim, void *stream) {
+                                  float *dxsum, float *stats, int rows, int dim, void *stream) {
     ACAI_CHECK_ARG(x && w && dy && dx && stats && rows >= 0 && dim > 0, "acai_layernorm_bwd: bad arguments");
     ACAI_CHECK_ARG((dw == nullptr) == (db == nullptr), "acai_layernorm_bwd: dw and db come together");
     if (rows == 0) return 0;
@@ -360,15 +367,15 @@ extern "C" int acai_layernorm_bwd(const float *x, const float *w, const float *d
         const dim3 grid(cdiv(rows, rpb));
         bf16_t *xb = (bf16_t *)dx_bf16;
         switch (dim / 256) {
-            case 1: hipLaunchKernelGGL(ln_bwd_fused_kernel<1>, grid, dim3(256), 0, st, x, w, dy, eps, dx, xb, dw, db, rows, rpb); break;
-            case 2: hipLaunchKernelGGL(ln_bwd_fused_kernel<2>, grid, dim3(256), 0, st, x, w, dy, eps, dx, xb, dw, db, rows, rpb); break;
-            case 3: hipLaunchKernelGGL(ln_bwd_fused_kernel<3>, grid, dim3(256), 0, st, x, w, dy, eps, dx, xb, dw, db, rows, rpb); break;
-            default: hipLaunchKernelGGL(ln_bwd_fused_kernel<4>, grid, dim3(256), 0, st, x, w, dy, eps, dx, xb, dw, db, rows, rpb); break;
+            case 1: hipLaunchKernelGGL(ln_bwd_fused_kernel<1>, grid, dim3(256), 0, st, x, w, dy, eps, dx, xb, dw, db, dxsum, rows, rpb); break;
+            case 2: hipLaunchKernelGGL(ln_bwd_fused_kernel<2>, grid, dim3(256), 0, st, x, w, dy, eps, dx, xb, dw, db, dxsum, rows, rpb); break;
+            case 3: hipLaunchKernelGGL(ln_bwd_fused_kernel<3>, grid, dim3(256), 0, st, x, w, dy, eps, dx, xb, dw, db, dxsum, rows, rpb); break;
+            default: hipLaunchKernelGGL(ln_bwd_fused_kernel<4>, grid, dim3(256), 0, st, x, w, dy, eps, dx, xb, dw, db, dxsum, rows, rpb); break;
         }
         ACAI_LAUNCH_CHECK("acai_layernorm_bwd");
         return 0;
     }
-    ACAI_CHECK_ARG(!dx_bf16, "acai_layernorm_bwd: the bf16 copy of dx needs dim %% 256 == 0, dim <= 1024 and 16-byte aligned operands");
+    ACAI_CHECK_ARG(!dx_bf16 && !dxsum, "acai_layernorm_bwd: the bf16 copy / column sums of dx need dim %% 256 == 0, dim <= 1024 and 16-byte aligned operands");
     hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, w, dy, eps, dx, stats, rows, dim);
     if (dw && db) {
         const int rpb = 2048;

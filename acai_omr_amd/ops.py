@@ -303,19 +303,24 @@ def dropout_add(x, residual, p, seed, out_dtype=None):
     return out
 
 
-def layernorm_bwd(x, w, dy, eps, want_param_grads=True, want_bf16=False):
-    """Returns (dx, dw, db) or, with want_bf16 (dim % 256 == 0, dim <= 1024), (dx, dw, db, dx_bf16)."""
+def layernorm_bwd(x, w, dy, eps, want_param_grads=True, want_bf16=False, want_colsum=False):
+    """Returns (dx, dw, db) or, with want_bf16 (dim % 256 == 0, dim <= 1024), (dx, dw, db, dx_bf16); want_colsum appends the column sums of
+    dx (of its bf16 copy when one is written): the bias gradient of the nn.Linear whose output this LayerNorm normalised."""
     _chk(x, "x", torch.float32), _chk(dy, "dy", torch.float32)
     assert x.is_contiguous() and dy.is_contiguous() and x.shape == dy.shape
     rows, dim = x.shape
     dx = torch.empty_like(x)
     dxb = torch.empty(rows, dim, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
     stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
-    dw = torch.zeros(dim, dtype=torch.float32, device=x.device) if want_param_grads else None
-    db = torch.zeros(dim, dtype=torch.float32, device=x.device) if want_param_grads else None
-    _lib.check(_lib.lib().acai_layernorm_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), float(eps), dx.data_ptr(), _p(dxb), _p(dw), _p(db),
+    n_acc = (2 if want_param_grads else 0) + (1 if want_colsum else 0)
+    acc = torch.zeros(max(n_acc, 1), dim, dtype=torch.float32, device=x.device)   # one fill for every accumulated vector
+    dw = acc[0] if want_param_grads else None
+    db = acc[1] if want_param_grads else None
+    dcs = acc[n_acc - 1] if want_colsum else None
+    _lib.check(_lib.lib().acai_layernorm_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), float(eps), dx.data_ptr(), _p(dxb), _p(dw), _p(db), _p(dcs),
                                              stats.data_ptr(), rows, dim, _st()), "acai_layernorm_bwd")
-    return (dx, dw, db, dxb) if want_bf16 else (dx, dw, db)
+    out = (dx, dw, db, dxb) if want_bf16 else (dx, dw, db)
+    return out + (dcs,) if want_colsum else out
 
 
 def gelu_fwd(a):

@@ -52,8 +52,8 @@ _SIDE = []
 SIDE_HITS = [0, 0]   # [hits, misses]: test / profiling aid
 
 
-def _side_put(t, tb):
-    _SIDE[:] = [(t, tb)]
+def _side_put(t, tb, colsum=None):
+    _SIDE[:] = [(t, tb, colsum)]
 
 
 _FWD_SIDE = []   # forward twin: bf16 copy of a LayerNorm output, consumed by the cast in front of the next bf16 GEMM
@@ -72,13 +72,18 @@ def _fwd_take(t):
     return None
 
 
-def _side_take(t):
+def _side_take2(t):
+    """(bf16 copy or None, column sums or None) that the producer of gradient `t` (LayerNorm backward) left for its consumer."""
     e = _SIDE.pop() if _SIDE else None
     if e is not None and e[0] is t:
         SIDE_HITS[0] += 1
-        return e[1]
+        return e[1], e[2]
     SIDE_HITS[1] += 1
-    return None
+    return None, None
+
+
+def _side_take(t):
+    return _side_take2(t)[0]
 
 
 # ---- autograd Functions ---------------------------------------------------------------------------------------------------
@@ -101,16 +106,10 @@ class LinearFn(Function):
         prec, bf = ctx.prec, ctx.prec == "bf16"
         dy = dy.contiguous()
         dres = dy if ctx.has_res else None
-        dyc = dy
-        if bf and dy.dtype != torch.bfloat16:
-            dyc = _side_take(dy)
-            if dyc is None:
-                dyc = ops.cast_bf16(dy)
-        elif not bf and dy.dtype != torch.float32:
-            dyc = dy.float()
+        dyc, cs = _grad_copy_cs(dy, prec)
         dx = ops.gemm_nt(dyc, ctx.wc.wt(W, prec), out_dtype=x.dtype) if ctx.needs_input_grad[0] else None
         dW = ops.gemm(dyc, x, trans_a=True, trans_w=True, out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
-        db = ops.colsum(dyc) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        db = (cs if cs is not None else ops.colsum(dyc)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dW, db, dres, None, None, None
 
 
@@ -122,15 +121,23 @@ def _compute_copy(x32, prec):
     return xb if xb is not None else ops.cast_bf16(x32)
 
 
-def _grad_copy(dy, prec):
-    """Incoming gradient in the compute dtype (the bf16 copy LayerNorm backward emitted, else one cast)."""
+def _grad_copy_cs(dy, prec):
+    """Incoming gradient in the compute dtype (the bf16 copy LayerNorm backward emitted, else one cast) and, when the producer formed them,
+    its column sums (= this Linear's bias gradient)."""
     bf = prec == "bf16"
     if bf and dy.dtype != torch.bfloat16:
-        dyc = _side_take(dy)
-        return dyc if dyc is not None else ops.cast_bf16(dy)
+        dyc, cs = _side_take2(dy)
+        return (dyc, cs) if dyc is not None else (ops.cast_bf16(dy), None)
     if not bf and dy.dtype != torch.float32:
-        return dy.float()
-    return dy
+        return dy.float(), None
+    if not bf:
+        _, cs = _side_take2(dy)
+        return dy, cs
+    return dy, None
+
+
+def _grad_copy(dy, prec):
+    return _grad_copy_cs(dy, prec)[0]
 
 
 class MlpFn(Function):
@@ -156,10 +163,10 @@ class MlpFn(Function):
         x, a, h, W1, W2 = ctx.saved_tensors
         prec, wc, bf = ctx.prec, ctx.wc, ctx.prec == "bf16"
         dy = dy.contiguous()
-        dyc = _grad_copy(dy, prec)
+        dyc, cs = _grad_copy_cs(dy, prec)
         da = ops.gemm_nt(dyc, wc.wt(W2, prec), out_dtype=a.dtype, round_bf16=bf, gelu_grad_of=a)     # (dY . W2) o gelu'(a)
         dW2 = ops.gemm(dyc, h, trans_a=True, trans_w=True, out_dtype=torch.float32) if ctx.needs_input_grad[3] else None
-        db2 = ops.colsum(dyc) if ctx.needs_input_grad[4] else None
+        db2 = (cs if cs is not None else ops.colsum(dyc)) if ctx.needs_input_grad[4] else None
         dx = None
         if ctx.needs_input_grad[0]:   # branch gradient (rounded to the compute dtype as the unfused path does) + residual gradient, fp32
             dx = ops.gemm_nt(da, wc.wt(W1, prec), residual=dy.float() if dy.dtype != torch.float32 else dy, out_dtype=torch.float32, round_bf16=bf)
@@ -194,10 +201,10 @@ class SelfAttnBlockFn(Function):
         bf = prec == "bf16"
         E = H * dh
         dy = dy.contiguous()
-        dyc = _grad_copy(dy, prec)
+        dyc, cs = _grad_copy_cs(dy, prec)
         dattn = ops.gemm_nt(dyc, wc.wt(Wo, prec), out_dtype=attn.dtype, round_bf16=bf)
         dWo = ops.gemm(dyc, attn, trans_a=True, trans_w=True, out_dtype=torch.float32) if ctx.needs_input_grad[3] else None
-        dbo = ops.colsum(dyc) if ctx.needs_input_grad[4] else None
+        dbo = (cs if cs is not None else ops.colsum(dyc)) if ctx.needs_input_grad[4] else None
         dqkv = torch.empty_like(qkv)
         ops.attn_varlen_bwd(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], attn, dattn, lse, cu, cu, H, dh, max_len, max_len, causal,
                             dqkv[:, :E], dqkv[:, E:2 * E], dqkv[:, 2 * E:])
@@ -210,6 +217,7 @@ class SelfAttnBlockFn(Function):
 
 
 _FUSED_MLP = os.environ.get("ACAI_FUSED_MLP", "1") != "0"   # A/B aid
+_LN_COLSUM = os.environ.get("ACAI_LN_COLSUM", "1") != "0"   # A/B aid: LayerNorm backward also forms the consuming Linear's bias gradient
 
 
 def _mlp(x32, lin1, lin2, p_inner, p_out, prec, wc):
@@ -307,15 +315,23 @@ class LayerNormFn(Function):
             _fwd_put(y, yb)   # the next bf16 GEMM reads this copy instead of casting y again
         ctx.save_for_backward(x, w)
         ctx.eps = eps
+        ctx.autocast = bf
         ctx.bf = bf and x.shape[1] % 256 == 0 and x.shape[1] <= 1024   # the consumer of dx is a bf16 GEMM
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        if ctx.bf:
+        fused = x.shape[1] % 256 == 0 and x.shape[1] <= 1024   # the one-pass kernel: can also leave dx's column sums for the consumer
+        if ctx.bf and not _LN_COLSUM:
             dx, dw, db, dxb = ops.layernorm_bwd(x, w.detach(), dy.contiguous().float(), ctx.eps, want_bf16=True)
             _side_put(dx, dxb)
+        elif ctx.bf:
+            dx, dw, db, dxb, cs = ops.layernorm_bwd(x, w.detach(), dy.contiguous().float(), ctx.eps, want_bf16=True, want_colsum=True)
+            _side_put(dx, dxb, cs)
+        elif fused and not ctx.autocast and _LN_COLSUM:
+            dx, dw, db, cs = ops.layernorm_bwd(x, w.detach(), dy.contiguous().float(), ctx.eps, want_colsum=True)
+            _side_put(dx, None, cs)
         else:
             dx, dw, db = ops.layernorm_bwd(x, w.detach(), dy.contiguous().float(), ctx.eps)
         return dx, dw, db, None

@@ -118,9 +118,9 @@ int acai_attn_varlen_bwd(const void *q, int ldq, const void *k, int ldk, const v
                          int total_q, int causal, int dtype, float dropout_p, uint32_t dropout_seed, void *stream);
 
 /* Backward of nn.LayerNorm: dx (fp32) from x, w, dy; dw/db (both or neither NULL) are ACCUMULATED with fp32 atomics (zero or seed
- * them); dx_bf16 (may be NULL; needs dim % 256 == 0, dim <= 1024): bf16 copy of dx for the GEMM that consumes it; stats: workspace
- * [rows][2]. */
-int acai_layernorm_bwd(const float *x, const float *w, const float *dy, float eps, float *dx, void *dx_bf16, float *dw, float *db,
+ * them); dx_bf16 (may be NULL; needs dim % 256 == 0, dim <= 1024): bf16 copy of dx for the GEMM that consumes it; dxsum (may be NULL, same
+ * condition; ACCUMULATED): column sums of dx as that GEMM sees it = the consuming nn.Linear's bias gradient; stats: workspace [rows][2]. */
+int acai_layernorm_bwd(const float *x, const float *w, const float *dy, float eps, float *dx, void *dx_bf16, float *dw, float *db, float *dxsum,
                        float *stats, int rows, int dim, void *stream);
 /* exact-erf GELU as a stand-alone pass (training keeps the pre-activation) and its derivative: da = dh * gelu'(a). */
 int acai_gelu_fwd(const void *a, void *h, int64_t n, int dtype, void *stream);

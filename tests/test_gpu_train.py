@@ -316,8 +316,11 @@ def test_layernorm_bwd_fused_and_colsum_vec(dev, dim):
     xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
     torch.nn.functional.layer_norm(xr, (dim,), wr, br, 1e-5).backward(dy)
     if dim % 256 == 0:
-        dx, dw, db, dxb = ops.layernorm_bwd(x, w, dy, 1e-5, want_bf16=True)
+        dx, dw, db, dxb, cs = ops.layernorm_bwd(x, w, dy, 1e-5, want_bf16=True, want_colsum=True)
         assert torch.equal(dxb, dx.to(torch.bfloat16))
+        assert torch.allclose(cs, dxb.float().sum(0), atol=2e-3, rtol=1e-3)          # column sums of the bf16 copy (the consuming Linear's bias gradient)
+        dx2, _, _, cs2 = ops.layernorm_bwd(x, w, dy, 1e-5, want_colsum=True)
+        assert torch.equal(dx2, dx) and torch.allclose(cs2, dx.sum(0), atol=2e-3, rtol=1e-3)
     else:
         dx, dw, db = ops.layernorm_bwd(x, w, dy, 1e-5)
     assert torch.allclose(dx, xr.grad, atol=2e-5, rtol=1e-4)
