@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_mfma_kernel(SkinnyArgs a) {
 //   * one wave reduced and finished all 4 x 64 outputs: here wave i finishes accumulator register i of every lane (4 waves in parallel).
 typedef __attribute__((vector_size(16))) unsigned int skm_v4u;
 
-template <bool XBF16, int LN, int NW>   // LN: 0 = none, 1 = LayerNorm on load, 2 = two LayerNorms in a row (unembed: norm3 of the last layer, then the final norm)
+template <bool XBF16, int LN, int NW, bool WFIRST = false>   // LN: 0 = none, 1 = LayerNorm on load, 2 = two LayerNorms in a row (unembed: norm3 of the last layer, then the final norm)
 __global__ __launch_bounds__(64 * NW) void skinny_chain_kernel(SkinnyArgs a) {
     constexpr bool HAS_LN = LN > 0;
     constexpr int K = 256 * NW, PITCH = K * 2 + 16;
@@ -463,9 +463,10 @@ __global__ __launch_bounds__(64 * NW) void skinny_chain_kernel(SkinnyArgs a) {
             const bf16_t *xr = reinterpret_cast<const bf16_t *>(a.x) + (size_t)(bt + (c >> 1)) * a.ldx + (c & 1) * (K / 2) + lane * 8;
             unsigned char *xd = xs + (c >> 1) * PITCH + ((c & 1) * (K / 2) + lane * 8) * 2;
             static_assert(!XBF16 || K == 4096, "four 16-byte pieces per lane and chunk");   // (named registers: an array here went to scratch)
+            if (first && WFIRST) request_weights();   // A/B: the HBM round trip (long) requested ahead of the L2 one
             const uint4 x0 = *reinterpret_cast<const uint4 *>(xr), x1 = *reinterpret_cast<const uint4 *>(xr + 512),
                         x2 = *reinterpret_cast<const uint4 *>(xr + 1024), x3 = *reinterpret_cast<const uint4 *>(xr + 1536);
-            if (first) request_weights();
+            if (first && !WFIRST) request_weights();
             __builtin_amdgcn_sched_barrier(0);
             *reinterpret_cast<uint4 *>(xd) = x0;
             *reinterpret_cast<uint4 *>(xd + 1024) = x1;
@@ -673,12 +674,16 @@ int launch_skinny(const SkinnyArgs &a, hipStream_t st) {
                 static bool attr2 = false;
                 if (!attr2) {
                     hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_chain_kernel<true, 0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_chain_kernel<true, 0, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
                     attr2 = true;
                 }
                 const dim3 cgrid(cdiv(a.N, b.rows_per_block), cdiv(a.B, 16));
                 const int nw = a.x_bf16 ? 16 : 4;
                 const size_t clds = (size_t)nw * 1024 + (size_t)rows * (a.K * 2 + 16);
-                if (a.x_bf16)
+                static const bool wfirst = getenv("ACAI_LIN2_WFIRST") && atoi(getenv("ACAI_LIN2_WFIRST")) == 1;   // A/B aid
+                if (a.x_bf16 && wfirst)
+                    hipLaunchKernelGGL((skinny_chain_kernel<true, 0, 16, true>), cgrid, dim3(1024), clds, st, b);
+                else if (a.x_bf16)
                     hipLaunchKernelGGL((skinny_chain_kernel<true, 0, 16>), cgrid, dim3(1024), clds, st, b);
                 else if (a.ln_w && a.ln2_w)
                     hipLaunchKernelGGL((skinny_chain_kernel<false, 2, 4>), cgrid, dim3(256), clds, st, b);

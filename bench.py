@@ -23,6 +23,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import torch
@@ -441,6 +442,7 @@ def main():
     ap.add_argument("--mae-dtype", default="bf16", choices=["fp32", "bf16"])
     ap.add_argument("--legs", default=None, help="comma list of mae,tf,ragged,config5 (default: mae,tf,ragged at N = 1; mae,config5 at N > 1)")
     ap.add_argument("--no-mae", action="store_true")
+    ap.add_argument("--leg-timeout", type=float, default=420.0, help="seconds the secondary legs may take before the line is printed without them")
     a = ap.parse_args()
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
@@ -550,18 +552,36 @@ def main():
     del vitomr
     torch.cuda.empty_cache()
 
-    mae_res = _leg(bench_mae, dev, rank, world, dist, a.mae_batch, a.height, a.width, a.mae_steps, a.mae_dtype, want_cpu) if "mae" in legs else None
-    tf_res = _leg(bench_tf_step, dev, 16, a.height, a.width, 512, 2) if ("tf" in legs and world == 1) else None
-    rag_res = _leg(bench_ragged_decode, dev, 512) if ("ragged" in legs and world == 1) else None
-    c5_res = _leg(bench_config5, dev, rank, world, dist, 32, 512, 2) if "config5" in legs else None
+    # The headline is measured.  The secondary legs must never cost it: an exception inside one is caught (`_leg`), and a HANG (a collective that
+    # one rank never reaches) is cut by a watchdog on every rank - after `--leg-timeout` seconds rank 0 prints the line with what it has and every
+    # rank leaves the process.
+    res = dict(mae=None, tf_step=None, ragged_decode=None, config5=None)
+    printed = threading.Event()
 
-    if rank == 0:
+    def emit(timed_out):
+        if printed.is_set():
+            return
+        printed.set()
+        if rank != 0:
+            return
+        out = build_line(res, timed_out)
+        print(json.dumps(out), flush=True)
+
+    def watchdog():
+        if not printed.wait(a.leg_timeout):
+            emit(True)
+            os._exit(0)
+
+    def build_line(res, timed_out):
+        mae_res, tf_res, rag_res, c5_res = res["mae"], res["tf_step"], res["ragged_decode"], res["config5"]
         out = dict(metric="LMX tokens/sec (greedy decode, KV cache)", value=tokens / dt, unit="tokens/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
                    ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
                    config=dict(workload=f"vitomr_greedy_decode batch {a.batch}/GPU of {a.height}x{a.width} images ({S} patches), decode steps {a.warmup + 1}..{a.warmup + a.steps}" + ("" if a.warmup + a.steps <= cap else f" (re-armed every {cap} steps)"),
                                batch_per_gpu=a.batch, memory_len=S, decoder="12 x d1024 h16 mlp4096, V=227", hipgraph=True),
                    prefill_ms=prefill_s * 1e3, prefill_encoder_dtype=a.encoder_dtype, roofline=roof, cpu_baseline=cpu, mae=mae_res, tf_step=tf_res,
                    ragged_decode=rag_res, config5=c5_res)
+        if timed_out:
+            out["legs_timed_out"] = f"secondary legs did not finish within {a.leg_timeout} s; fields still None were not measured"
         # decode-only (`value`) and end to end.  Composed from the two measured parts - the prefill timed once above and the timed
         # decode steps - for a generation of 288 tokens per sequence (the default warmup + steps); not a separately timed run.
         gen = 288
@@ -569,7 +589,18 @@ def main():
                                  includes=f"encoder ({a.encoder_dtype}) + transition head + cross-K/V prefill (measured once) + {gen} decode steps at the measured step time")
         if cpu is not None:
             out["gpu_over_cpu"] = out["value"] / cpu["value"]
-        print(json.dumps(out), flush=True)
+        return out
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    if "mae" in legs:
+        res["mae"] = _leg(bench_mae, dev, rank, world, dist, a.mae_batch, a.height, a.width, a.mae_steps, a.mae_dtype, want_cpu)
+    if "tf" in legs and world == 1:
+        res["tf_step"] = _leg(bench_tf_step, dev, 16, a.height, a.width, 512, 2)
+    if "ragged" in legs and world == 1:
+        res["ragged_decode"] = _leg(bench_ragged_decode, dev, 512)
+    if "config5" in legs:
+        res["config5"] = _leg(bench_config5, dev, rank, world, dist, 32, 512, 2)
+    emit(False)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
