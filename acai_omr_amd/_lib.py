@@ -10,7 +10,7 @@ import subprocess
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(CSRC, "libacai_omr_hip.so")
+LIB_PATH = os.environ.get("ACAI_OMR_LIB") or os.path.join(CSRC, "libacai_omr_hip.so")   # (override: A/B builds of the same sources, tools/ab_*.sh)
 SOURCES = ["gemm.hip", "elementwise.hip", "attn_varlen.hip", "attn_bwd.hip", "train.hip", "decode.hip", "resize.hip"]
 
 ACAI_F32, ACAI_BF16 = 0, 1

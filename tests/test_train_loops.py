@@ -48,12 +48,6 @@ def test_prepare_lmx_sequence_and_constants():
     ft = loops.FINE_TUNE
     assert (ft["epochs"], ft["base_lr"], ft["fine_tune_base_lr"], ft["fine_tune_decay_factor"], ft["weight_decay"], ft["grad_accumulation_steps"]) == \
         (40, 1e-4, 1e-5, 0.9, 0.01, 8) and ft["soft_epochs"] == ft["epochs"] // 2 and ft["tf_anneal_epochs"] == 35
-    # import-path mirrors of the two reference modules
-    import acai_omr_amd.train.omr_teacher_force_train as ft_mod
-    import acai_omr_amd.train.pre_train as pt_mod
-    assert pt_mod.train_loop is loops.pretrain_epoch and pt_mod.validation_loop is loops.pretrain_validation and pt_mod.BASE_LR == 1.5e-4
-    assert ft_mod.train_loop is loops.fine_tune_epoch and ft_mod.TFScheduler is loops.TFScheduler and ft_mod.GRAD_ACCUMULATION_STEPS == 8
-    assert (ft_mod.INITIAL_TAU, ft_mod.MIN_TAU, ft_mod.SOFT_EPOCHS, ft_mod.DECODER_DROPOUT) == (5.0, 0.1, 20, 0.1)
     c = loops.StepCounter()
     c.increment()
     assert c.global_step == 1

@@ -9,6 +9,7 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 dev = torch.device("cuda", 0)
 only = os.environ.get("ACAI_BENCH_ATTN_ONLY")
 for name, B, H, S, dh, dt in (("mae-decoder", 32, 16, 4096, 32, torch.bfloat16), ("mae-encoder", 32, 12, 1024, 64, torch.bfloat16),
+                              ("tf-encoder", 16, 12, 4096, 64, torch.bfloat16),
                               ("omr-encoder-fp32", 8, 12, 4096, 64, torch.float32)):
     if only and name != only:
         continue
