@@ -1017,6 +1017,112 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     epi_half(std::integral_constant<int, 1>{});
 }
 
+// ---- dW = dY^T X on the three-stage ring (round 2) -------------------------------------------------------------------------------------
+// gemm_tn_glds_kernel keeps ONE 64-token tile in flight per workgroup (two stages, `__syncthreads()` drains the LDS-DMA): a K-step of a
+// 128x128 tile is ~0.2 us of MFMA work against >= 1 us of loaded fabric latency, and two co-resident workgroups do not cover it (0.61-0.69 PF
+// on the MAE's weight gradients).  This form is the NT ring's structure on the token-major operands: 256 (dY columns) x 128 (X columns) tile,
+// 8 waves as 4 x 2, THREE 48 KB stages (two [64 tokens][128 col] images of dY, one of X, each in gemm_tn_glds_kernel's swizzled layout and
+// read with the same transposing fragment reads), two K-tiles in flight behind a counted `s_waitcnt vmcnt(6)` and ONE raw barrier per K-step,
+// LDS-DMA issued from inline asm so the compiler's wait-count pass never sees it.  Split-K over the tokens, fp32 atomics per 32x32 block.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void gemm_tn_ring_kernel(GemmArgs g) {
+    typedef bf16_t T;
+    constexpr int BKT = 64, IMG = BKT * 256, STAGE = 3 * IMG, BMT = 256;   // 16 KB per image, 48 KB per stage
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+    const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BMT - 1) / BMT, nwg = nbn * nbm;
+    int pid = blockIdx.x, kslice = 0;
+    if (g.ksplit > 1) {
+        kslice = pid / nwg;
+        pid -= kslice * nwg;
+    }
+    const int bm0 = (pid / nbn) * BMT, bn0 = (pid % nbn) * BN;
+    int nkt = g.K / BKT, kt_begin = 0;
+    if (g.ksplit > 1) {
+        const int per = (nkt + g.ksplit - 1) / g.ksplit;
+        kt_begin = kslice * per;
+        nkt = min(nkt, kt_begin + per);
+        if (kt_begin >= nkt) return;  // uniform per workgroup, before any barrier
+    }
+    const int nk = nkt - kt_begin;
+    const T *A = reinterpret_cast<const T *>(g.A);
+    const T *W = reinterpret_cast<const T *>(g.W);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // LDS-DMA instruction j (0..15) of an image covers token rows 4j .. 4j+3; lane l lands at row 4j + l/16, 16-byte unit l%16, which holds logical
+    // unit (l%16) ^ ((row & 3) << 2).  Wave w issues j = 2w, 2w+1 of each of the three images: six instructions per wave and K-tile.
+    // Columns beyond M / N are clamped to the last whole chunk (their outputs are never stored).
+    const T *src[6];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 4 + (lane >> 4);
+        const int u = (lane & 15) ^ ((r & 3) << 2);
+        src[i] = A + (size_t)r * g.lda + min(bm0 + u * 8, g.M - 8);
+        src[2 + i] = A + (size_t)r * g.lda + min(bm0 + 128 + u * 8, g.M - 8);
+        src[4 + i] = W + (size_t)r * g.ldw + min(bn0 + u * 8, g.N - 8);
+    }
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr)lds;
+    auto issue = [&](int kt, int slot) {
+        const uint32_t lb = lds_base + slot * STAGE;
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t dst = __builtin_amdgcn_readfirstlane(lb + m * IMG + (wave * 2 + i) * 1024);
+                glds16(dst, src[2 * m + i] + (size_t)kt * BKT * (m == 2 ? g.ldw : g.lda));
+            }
+    };
+    typedef __attribute__((ext_vector_type(4))) short s4;
+    typedef __attribute__((address_space(3))) s4 *lds_s4;
+    const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+    // fragment of output rows rowbase .. rowbase+31 of one 128-column image, contraction slice s: element j of lane half h is token 16 s + 8 h + j
+    auto frag = [&](const unsigned char *img, int rowbase, int s) -> uint4 {
+        const int m = 16 * s + 8 * lh + (i16 >> 2), bc = (rowbase + 16 * g1 + 4 * (i16 & 3)) * 2;
+        const int o = m * 256 + ((((bc >> 6) ^ (m & 3))) << 6) + (bc & 63);   // rows m and m + 4 share (m & 3)
+        union { s4 v[2]; uint4 u; } r;
+        r.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(img + o));
+        r.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(img + o + 4 * 256));
+        return r.u;
+    };
+    const int a_img = (wm >> 1) * IMG, a_row = (wm & 1) * 64;   // this wave's 64 dY columns: image wm / 2, rows (wm % 2) * 64 ..
+    auto compute = [&](const unsigned char *st) {
+        const unsigned char *sa = st + a_img, *sb = st + 2 * IMG;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            uint4 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = frag(sa, a_row + i * 32, s);
+                fb[i] = frag(sb, wn * 64 + i * 32, s);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+        }
+    };
+    issue(kt_begin, 0);
+    if (nk > 1) issue(kt_begin + 1, 1);
+    int slot = 0;
+    for (int q = 0; q < nk; ++q) {
+        if (q + 1 < nk)
+            asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");   // this wave's six pieces of tile q have landed (tile q + 1 may still fly); everybody's have
+        else
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (q + 2 < nk) issue(kt_begin + q + 2, slot == 0 ? 2 : slot - 1);   // the stage read in step q - 1: every wave is past it
+        compute(lds + slot * STAGE);
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    gemm_accum_epilogue(g, acc, bm0, bn0, wm, wn, lr, lh);
+}
+
 int g_gemm_variant = getenv("ACAI_GEMM_VARIANT") ? atoi(getenv("ACAI_GEMM_VARIANT")) : 0;
 
 template <typename T, int EPI, bool TA = false, bool TB = false>
@@ -1048,6 +1154,16 @@ int launch(const GemmArgs &g, hipStream_t st) {
             const int k64 = g.K - g.K % 64;
             GemmArgs m = h;
             m.K = k64;
+            // the three-stage ring (256 x 128 tiles, one workgroup per CU) when the reduction is long enough to fill it: split K until ~256 workgroups exist
+            static const bool no_ring = getenv("ACAI_GEMM_TN_RING") && atoi(getenv("ACAI_GEMM_TN_RING")) == 0;   // A/B aid
+            const int tiles_r = cdiv(g.M, 256) * cdiv(g.N, BN), nkt_r = k64 / 64;
+            int ks_r = 256 / tiles_r;            // one resident workgroup per CU: never more workgroups than CUs (a second, nearly empty round doubles the time)
+            if (ks_r < 1) ks_r = 1;
+            if (ks_r > nkt_r / 8) ks_r = nkt_r / 8;
+            if (!no_ring && ks_r >= 1 && nkt_r >= 16) {
+                m.ksplit = ks_r;
+                hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3(tiles_r * ks_r), dim3(512), 0, st, m);
+            } else
             hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(nwg), dim3(256), 0, st, m);
             if (k64 < g.K) {
                 GemmArgs t = h;
