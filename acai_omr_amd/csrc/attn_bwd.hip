@@ -13,6 +13,12 @@
 // of 5) - the price of having no cross-workgroup reduction.  fp32: v_mfma_f32_32x32x2_f32, bf16: v_mfma_f32_32x32x16_bf16.
 #include "common.h"
 #include <type_traits>
+#ifndef ACAI_DKV_STRAIGHT
+#define ACAI_DKV_STRAIGHT 0
+#endif
+#ifndef ACAI_DKV_WAVES
+#define ACAI_DKV_WAVES 3
+#endif
 
 namespace {
 
@@ -183,7 +189,7 @@ struct TileStager {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int DHP, bool FAST, bool DROP>
+template <typename T, int DHP, bool FAST, bool DROP, bool PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dq_kernel(BwdArgs a) {
     constexpr int ES = sizeof(T);
     constexpr int RP = TileLayout<ES, DHP>::PITCH;   // pitch of the natural [row][d] tiles
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
             }
         }
         dlt += __shfl_xor(dlt, 32);
-        if (lh == 0 && my_q < lq) const_cast<float *>(a.delta)[sidx] = dlt;
+        if (lh == 0 && my_q < lq) const_cast<float *>(a.delta)[sidx] = -dlt;   // negated: it is the dK/dV kernel's dP accumulator start, as loaded
     }
 
     f32x16 dqacc[NDB];
@@ -245,44 +251,80 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 
     int nkt = (lk + TT - 1) / TT;
     if (a.causal) nkt = min(nkt, (min(q0 + OB, lq) - 1) / TT + 1);
+    // PRE: q arrives as q * log2(e) / sqrt(d_h) (see acai_attn_varlen_fwd), so K . Q^T is the exponent's first term itself; the score
+    // accumulators then START at -lse and the MFMA leaves (score - lse): one exp2 per probability and nothing else
+    const float c = PRE ? 1.0f : a.scale_log2e;
+    f32x16 sinit, pinit;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        sinit[e] = PRE ? -lse : 0.f;
+        pinit[e] = DROP ? 0.f : -dlt;   // without dropout dP starts at -delta (a per-lane scalar here): dP - delta leaves the MFMA for free
+    }
+    const float dsub = DROP ? dlt : 0.f;
     TileStager<T, DHP, FAST> stg;
     stg.init(K, a.ldk, V, a.ldv, tid, dh, 0);
     stg.load(0, lk);
     stg.store(smem);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
+
+    auto drop_dp = [&](int kt, int kb, f32x16 &dpacc) {  // dP = mask/(1-p) o (dO V^T)
+        const uint32_t rrow = (uint32_t)(h * a.total_q + q_start + my_q);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const uint32_t key = (uint32_t)(kt * TT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh);
+            dpacc[e] = drop_keep(a.drop_seed, rrow, key, a.drop_thr) ? dpacc[e] * a.drop_scale : 0.f;
+        }
+    };
+
+    // ---- fast loop: the leading tiles with every key valid (not causal).  One basic block per tile: the four S / dP products of both key
+    // blocks are in flight before the first exponential is needed, and the common tile carries 1 exp2 + 1 multiply per score and one pack per
+    // two (PRE).  The masked tiles live in their own loop below: sharing one loop body, the two paths' accumulator chains met in copies
+    // (16 v_mov per tile) and split the tile into blocks the scheduler could not cross.
+    constexpr bool STRAIGHT = !(ES == 4 && DHP == 64);   // fp32 d_h = 64 would spill with both blocks live: it stays in the general loop
+    const int n_fast = (STRAIGHT && !a.causal) ? min(nkt, lk / TT) : 0;
+    for (int kt = 0; kt < n_fast; ++kt) {
+        const unsigned char *ldsK = smem + (kt & 1) * STAGE, *ldsV = ldsK + TT * RP;
+        if (kt + 1 < nkt) stg.load(kt + 1, lk);
+        f32x16 s0 = sinit, p0 = pinit, s1 = sinit, p1 = pinit;
+        mma_rows2<T, DHP, NS>(s0, ldsK, qf, p0, ldsV, dof, 0, lr, lh);    // S^T[key][q] and dP^T[key][q] (- delta)
+        mma_rows2<T, DHP, NS>(s1, ldsK, qf, p1, ldsV, dof, 32, lr, lh);
+        if constexpr (DROP) {
+            drop_dp(kt, 0, p0);
+            drop_dp(kt, 1, p1);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s0[e] = (PRE ? fast_exp2(s0[e]) : fast_exp2(fmaf(s0[e], c, -lse))) * (p0[e] - dsub);   // dS^T
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) mma_acc<T, DHP>(dqacc[d], ldsK, 0, d * 32, lane, s0);  // dQ^T += K^T dS^T
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s1[e] = (PRE ? fast_exp2(s1[e]) : fast_exp2(fmaf(s1[e], c, -lse))) * (p1[e] - dsub);
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) mma_acc<T, DHP>(dqacc[d], ldsK, 32, d * 32, lane, s1);
+        if (kt + 1 < nkt) stg.store(smem + ((kt + 1) & 1) * STAGE);
+        __syncthreads();
+    }
+    // ---- general loop: ragged last tile, causal tiles ------------------------------------------------------------------------------------
+    for (int kt = n_fast; kt < nkt; ++kt) {
         const unsigned char *ldsK = smem + (kt & 1) * STAGE, *ldsV = ldsK + TT * RP;
         if (kt + 1 < nkt) stg.load(kt + 1, lk);
         const int key_lim = a.causal ? min(lk, my_q + 1) : lk;
         const bool interior = (kt + 1) * TT <= (a.causal ? min(lk, q0 + wave * 32 + 1) : lk);  // every key valid for the whole wave
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            // without dropout the accumulator of dP starts at -delta (a per-lane scalar here): dP - delta leaves the MFMA for free
-            f32x16 sacc, dpacc;
+            f32x16 sacc, dpacc = pinit;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                sacc[e] = 0.f;
-                dpacc[e] = DROP ? 0.f : -dlt;
-            }
-            mma_rows2<T, DHP, NS>(sacc, ldsK, qf, dpacc, ldsV, dof, kb * 32, lr, lh);   // S^T[key][q] and dP^T[key][q] (- delta)
-            if constexpr (DROP) {  // dP = mask/(1-p) o (dO V^T)
-                const uint32_t rrow = (uint32_t)(h * a.total_q + q_start + my_q);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const uint32_t key = (uint32_t)(kt * TT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh);
-                    dpacc[e] = drop_keep(a.drop_seed, rrow, key, a.drop_thr) ? dpacc[e] * a.drop_scale : 0.f;
-                }
-            }
-            const float dsub = DROP ? dlt : 0.f;
+            for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+            mma_rows2<T, DHP, NS>(sacc, ldsK, qf, dpacc, ldsV, dof, kb * 32, lr, lh);
+            if constexpr (DROP) drop_dp(kt, kb, dpacc);
             if (interior) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) sacc[e] = fast_exp2(fmaf(sacc[e], a.scale_log2e, -lse)) * (dpacc[e] - dsub);   // dS^T
+                for (int e = 0; e < 16; ++e) sacc[e] = fast_exp2(fmaf(sacc[e], c, -lse)) * (dpacc[e] - dsub);   // dS^T
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int key = kt * TT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    const float p = key < key_lim ? fast_exp2(sacc[e] * a.scale_log2e - lse) : 0.f;
-                    sacc[e] = p * (dpacc[e] - dsub);                        // dS^T
+                    const float pr = key < key_lim ? fast_exp2(sacc[e] * c - lse) : 0.f;
+                    sacc[e] = pr * (dpacc[e] - dsub);                        // dS^T
                 }
             }
 #pragma unroll
@@ -296,16 +338,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int dd = d * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (dd < dh) DT<T>::st(row + dd, dqacc[d][e] * a.scale);
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = d * 32 + 8 * g4 + 4 * lh;   // registers 4 g4 .. 4 g4 + 3 are four consecutive d: one 8- / 16-byte store
+                if constexpr (FAST) {
+                    if (d0 < dh) {
+                        if constexpr (ES == 2) {
+                            uint2 pk;
+                            pk.x = pack_bf16(dqacc[d][4 * g4 + 0] * a.scale, dqacc[d][4 * g4 + 1] * a.scale);
+                            pk.y = pack_bf16(dqacc[d][4 * g4 + 2] * a.scale, dqacc[d][4 * g4 + 3] * a.scale);
+                            *reinterpret_cast<uint2 *>(row + d0) = pk;
+                        } else {
+                            *reinterpret_cast<float4 *>(row + d0) = make_float4(dqacc[d][4 * g4 + 0] * a.scale, dqacc[d][4 * g4 + 1] * a.scale,
+                                                                               dqacc[d][4 * g4 + 2] * a.scale, dqacc[d][4 * g4 + 3] * a.scale);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (d0 + e < dh) DT<T>::st(row + d0 + e, dqacc[d][4 * g4 + e] * a.scale);
+                }
             }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int DHP, bool FAST, bool DROP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DHP == 64) ? 1 : ((sizeof(T) == 2 && DHP == 32) ? 3 : 2)))) void attn_bwd_dkv_kernel(BwdArgs a) {
+template <typename T, int DHP, bool FAST, bool DROP, bool PRE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && DHP == 64) ? 1 : ((sizeof(T) == 2 && DHP == 32) ? ACAI_DKV_WAVES : 2)))) void attn_bwd_dkv_kernel(BwdArgs a) {
     constexpr int ES = sizeof(T);
     constexpr int RP = TileLayout<ES, DHP>::PITCH;
     constexpr int NS = DHP * ES / 32, NDB = DHP / 32, STAGE = 2 * TT * RP + 2 * TT * (int)sizeof(float);
@@ -343,19 +401,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) 
     TileStager<T, DHP, FAST> stg;
     stg.init(Q, a.ldq, DO, a.lddo, tid, dh, qt0);
     const float *lse_row = a.lse + (size_t)h * a.total_q + q_start, *dlt_row = a.delta + (size_t)h * a.total_q + q_start;
-    float r_lse = 0.f, r_dlt = 0.f;
-    auto load_stats = [&](int qt) {   // threads 0..63: one query row's statistics each
-        if (tid < TT) {
-            const int qq = qt * TT + tid, qi = qq < lq ? qq : 0;
-            r_lse = lse_row[qi];
-            r_dlt = dlt_row[qi];
-        }
+    const float c = PRE ? 1.0f : a.scale_log2e;   // PRE: see attn_bwd_dq_kernel
+    // one query row's statistics per thread: threads 0..63 (and, redundantly, 128..191) fetch lse, 64..127 (192..255) -delta.  Every thread
+    // issues the load - under a `tid < 64` branch the compiler put s_waitcnt vmcnt in front of the tile's first MFMAs, which made every wave
+    // wait out its own prefetch of the next tile
+    float r_stat = 0.f;
+    const float *stat_row = (tid & 64) ? dlt_row : lse_row;
+    auto load_stats = [&](int qt) {
+        const int qq = qt * TT + (tid & 63);
+        r_stat = stat_row[qq < lq ? qq : 0];
     };
+    // both go to LDS NEGATED (attn_bwd_dq published -delta already): they are accumulator start values.  The sign flip sits here, a tile
+    // after the load, not next to it
     auto store_stats = [&](unsigned char *stage) {
-        if (tid < TT) {
-            reinterpret_cast<float *>(stage + 2 * TT * RP)[tid] = r_lse;
-            reinterpret_cast<float *>(stage + 2 * TT * RP)[TT + tid] = r_dlt;
-        }
+        if (tid < 2 * TT) reinterpret_cast<float *>(stage + 2 * TT * RP)[tid] = (tid & 64) ? r_stat : -r_stat;
     };
     if (qt0 < nqt) {
         stg.load(qt0, lq);
@@ -363,114 +422,188 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) 
         stg.store(smem);
         store_stats(smem);
     }
+    // Every global load so far (the K / V fragments above all) is complete on EVERY path into the loops.  Without this the path around the `if`
+    // leaves them pending as far as the compiler's wait-count bookkeeping knows, and it then puts s_waitcnt vmcnt(1) / vmcnt(0) in front of the
+    // first MFMAs of every tile that read those fragments - which waits out the prefetch of the next tile issued a few instructions earlier
+    // (PMC: 40 % of the wave cycles parked in s_waitcnt).
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt and lgkmcnt untouched
     __syncthreads();
-    for (int qt = qt0; qt < nqt; ++qt) {
-        const unsigned char *cur = smem + ((qt - qt0) & 1) * STAGE;
-        const unsigned char *ldsQ = cur, *ldsDO = cur + TT * RP;
-        const float *ldsLse = reinterpret_cast<const float *>(cur + 2 * TT * RP), *ldsDlt = ldsLse + TT;
-        if (qt + 1 < nqt) {
-            stg.load(qt + 1, lq);
-            load_stats(qt + 1);
+
+    // S[q][key] and dP[q][key] of one 32-query block.  The 16 query rows a lane holds are rows 8 g4 + 4 lh + (0..3): their statistics come as
+    // one 16-byte LDS read each, straight into the accumulators' start values: dP starts at -delta (dP - delta leaves the MFMA for free), and
+    // with PRE the score starts at -lse (the MFMA leaves score - lse: one exp2 per probability)
+    auto s_dp = [&](const unsigned char *cur, int qb, f32x16 &sacc, f32x16 &dpacc, f32x4 (&nlse4)[4], f32x4 (&ndl4)[4]) {
+        const float *ldsNlse = reinterpret_cast<const float *>(cur + 2 * TT * RP), *ldsNdl = ldsNlse + TT;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            nlse4[g4] = *reinterpret_cast<const f32x4 *>(ldsNlse + qb * 32 + 8 * g4 + 4 * lh);
+            ndl4[g4] = *reinterpret_cast<const f32x4 *>(ldsNdl + qb * 32 + 8 * g4 + 4 * lh);
         }
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            // row statistics of the 16 query rows this lane holds: rows 8 g4 + 4 lh + (0..3) are contiguous -> one 16-byte LDS read each
-            f32x4 lse4[4], dlt4[4];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                lse4[g4] = *reinterpret_cast<const f32x4 *>(ldsLse + qb * 32 + 8 * g4 + 4 * lh);
-                dlt4[g4] = *reinterpret_cast<const f32x4 *>(ldsDlt + qb * 32 + 8 * g4 + 4 * lh);
-            }
-            // without dropout the dP accumulator starts at -delta[row]: dP - delta leaves the MFMA for free
-            f32x16 sacc, dpacc;
+        for (int e = 0; e < 16; ++e) {
+            sacc[e] = PRE ? nlse4[e >> 2][e & 3] : 0.f;
+            dpacc[e] = DROP ? 0.f : ndl4[e >> 2][e & 3];
+        }
+        mma_rows2<T, DHP, NS>(sacc, cur, kf, dpacc, cur + TT * RP, vf, qb * 32, lr, lh);
+    };
+    // P and dS of the block (in place of S and dP), then dV^T += dO^T P and dK^T += Q^T dS.  mode 0: every (query, key) of the block is valid
+    auto ds_dkv = [&](const unsigned char *cur, int qt, int qb, f32x16 &sacc, f32x16 &dpacc, const f32x4 (&nlse4)[4], const f32x4 (&ndl4)[4], bool inter) {
+        const float s_off = PRE ? 0.f : 1.f;   // PRE: -lse is already inside sacc
+        if (DROP) {  // keep mask of (query row, my key): dP is masked, and so is the P that multiplies dO for dV
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                sacc[e] = 0.f;
-                dpacc[e] = DROP ? 0.f : -dlt4[e >> 2][e & 3];
+                const int ql = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, qq = qt * TT + ql;
+                const bool ok = qq < lq && my_k < lk && (!a.causal || my_k <= qq);
+                const float pr = ok ? fast_exp2(fmaf(sacc[e], c, s_off * nlse4[e >> 2][e & 3])) : 0.f;
+                const float mk = drop_keep(a.drop_seed, (uint32_t)(h * a.total_q + q_start + qq), (uint32_t)my_k, a.drop_thr) ? a.drop_scale : 0.f;
+                sacc[e] = pr * mk;                                                  // dropped P (for dV)
+                dpacc[e] = pr * (dpacc[e] * mk + ndl4[e >> 2][e & 3]);              // dS
             }
-            mma_rows2<T, DHP, NS>(sacc, ldsQ, kf, dpacc, ldsDO, vf, qb * 32, lr, lh);   // S[q][key] and dP[q][key] (- delta)
-            // interior: every query of the tile exists, every key of the WAVE exists and (causal) lies at or before the tile's first query
-            const bool interior = (qt + 1) * TT <= lq && k0 + wave * 32 + 32 <= lk && (!a.causal || k0 + wave * 32 + 31 <= qt * TT + qb * 32);
-            if (DROP) {  // keep mask of (query row, my key): dP is masked, and so is the P that multiplies dO for dV
+        } else if (inter) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int ql = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, qq = qt * TT + ql;
-                    const bool ok = qq < lq && my_k < lk && (!a.causal || my_k <= qq);
-                    const float p = ok ? fast_exp2(sacc[e] * a.scale_log2e - lse4[e >> 2][e & 3]) : 0.f;
-                    const float mk = drop_keep(a.drop_seed, (uint32_t)(h * a.total_q + q_start + qq), (uint32_t)my_k, a.drop_thr) ? a.drop_scale : 0.f;
-                    sacc[e] = p * mk;                                                  // dropped P (for dV)
-                    dpacc[e] = p * (dpacc[e] * mk - dlt4[e >> 2][e & 3]);              // dS
-                }
-            } else if (interior) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float p = fast_exp2(fmaf(sacc[e], a.scale_log2e, -lse4[e >> 2][e & 3]));
-                    sacc[e] = p;                                           // P
-                    dpacc[e] = p * dpacc[e];                               // dS (delta already subtracted)
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int ql = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, qq = qt * TT + ql;
-                    const bool ok = qq < lq && my_k < lk && (!a.causal || my_k <= qq);
-                    const float p = ok ? fast_exp2(sacc[e] * a.scale_log2e - lse4[e >> 2][e & 3]) : 0.f;
-                    sacc[e] = p;
-                    dpacc[e] = p * dpacc[e];
-                }
+            for (int e = 0; e < 16; ++e) {
+                const float pr = PRE ? fast_exp2(sacc[e]) : fast_exp2(fmaf(sacc[e], c, nlse4[e >> 2][e & 3]));
+                sacc[e] = pr;                                           // P
+                dpacc[e] = pr * dpacc[e];                               // dS (delta already subtracted)
             }
+        } else {
 #pragma unroll
-            for (int d = 0; d < NDB; ++d) {
-                mma_acc<T, DHP>(dvacc[d], ldsDO, qb * 32, d * 32, lane, sacc);   // dV^T += dO^T P
-                mma_acc<T, DHP>(dkacc[d], ldsQ, qb * 32, d * 32, lane, dpacc);   // dK^T += Q^T dS
+            for (int e = 0; e < 16; ++e) {
+                const int ql = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, qq = qt * TT + ql;
+                const bool ok = qq < lq && my_k < lk && (!a.causal || my_k <= qq);
+                const float pr = ok ? fast_exp2(fmaf(sacc[e], c, s_off * nlse4[e >> 2][e & 3])) : 0.f;
+                sacc[e] = pr;
+                dpacc[e] = pr * dpacc[e];
             }
         }
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) {
+            mma_acc<T, DHP>(dvacc[d], cur + TT * RP, qb * 32, d * 32, lane, sacc);   // dV^T += dO^T P
+            mma_acc<T, DHP>(dkacc[d], cur, qb * 32, d * 32, lane, dpacc);            // dK^T += Q^T dS
+        }
+    };
+    auto advance = [&](int qt) {
         if (qt + 1 < nqt) {
             unsigned char *nxt = smem + ((qt + 1 - qt0) & 1) * STAGE;
             stg.store(nxt);
             store_stats(nxt);
         }
         __syncthreads();
+    };
+
+    // ---- fast loop (not causal, every key of the workgroup valid): the leading full query tiles, without masks.  Its own loop for the reason
+    // given in attn_bwd_dq_kernel.  ACAI_DKV_STRAIGHT: both 32-query blocks in one basic block (needs the registers of two waves per SIMD at
+    // d_h = 32; three waves per SIMD with one block at a time measured faster - tools/ab_attn.sh)
+    const int n_fast = (!a.causal && k0 + OB <= lk) ? lq / TT : 0;
+    constexpr bool STRAIGHT = ACAI_DKV_STRAIGHT && !(ES == 2 && DHP == 64);
+    for (int qt = qt0; qt < n_fast; ++qt) {
+        const unsigned char *cur = smem + ((qt - qt0) & 1) * STAGE;
+        if (qt + 1 < nqt) {
+            stg.load(qt + 1, lq);
+            load_stats(qt + 1);
+        }
+        if constexpr (STRAIGHT) {
+            f32x16 s0, p0, s1, p1;
+            f32x4 l0[4], n0[4], l1[4], n1[4];
+            s_dp(cur, 0, s0, p0, l0, n0);
+            s_dp(cur, 1, s1, p1, l1, n1);
+            ds_dkv(cur, qt, 0, s0, p0, l0, n0, true);
+            ds_dkv(cur, qt, 1, s1, p1, l1, n1, true);
+        } else {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                f32x16 sacc, dpacc;
+                f32x4 nlse4[4], ndl4[4];
+                s_dp(cur, qb, sacc, dpacc, nlse4, ndl4);
+                ds_dkv(cur, qt, qb, sacc, dpacc, nlse4, ndl4, true);
+            }
+        }
+        advance(qt);
+    }
+    // ---- general loop: ragged tiles, causal tiles -----------------------------------------------------------------------------------------
+    for (int qt = max(qt0, n_fast); qt < nqt; ++qt) {
+        const unsigned char *cur = smem + ((qt - qt0) & 1) * STAGE;
+        if (qt + 1 < nqt) {
+            stg.load(qt + 1, lq);
+            load_stats(qt + 1);
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 sacc, dpacc;
+            f32x4 nlse4[4], ndl4[4];
+            s_dp(cur, qb, sacc, dpacc, nlse4, ndl4);
+            // interior block: every query of the tile exists, every key of the WAVE exists and (causal) lies at or before the block's first query
+            const bool inter = (qt + 1) * TT <= lq && k0 + wave * 32 + 32 <= lk && (!a.causal || k0 + wave * 32 + 31 <= qt * TT + qb * 32);
+            ds_dkv(cur, qt, qb, sacc, dpacc, nlse4, ndl4, inter);
+        }
+        advance(qt);
     }
     if (my_k < lk) {
         T *rk = DK + (size_t)my_k * a.lddk, *rv = DV + (size_t)my_k * a.lddv;
+        const float ksc = PRE ? 0.6931471805599453f : a.scale;   // PRE: dK = dS^T Q = dS^T Q' sqrt(d_h) / log2(e), times 1/sqrt(d_h)
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int dd = d * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (dd < dh) {
-                    DT<T>::st(rk + dd, dkacc[d][e] * a.scale);
-                    DT<T>::st(rv + dd, dvacc[d][e]);
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = d * 32 + 8 * g4 + 4 * lh;   // registers 4 g4 .. 4 g4 + 3 are four consecutive d: one 8- / 16-byte store each
+                if constexpr (FAST) {
+                    if (d0 < dh) {
+                        if constexpr (ES == 2) {
+                            uint2 pk, pv;
+                            pk.x = pack_bf16(dkacc[d][4 * g4 + 0] * ksc, dkacc[d][4 * g4 + 1] * ksc);
+                            pk.y = pack_bf16(dkacc[d][4 * g4 + 2] * ksc, dkacc[d][4 * g4 + 3] * ksc);
+                            pv.x = pack_bf16(dvacc[d][4 * g4 + 0], dvacc[d][4 * g4 + 1]);
+                            pv.y = pack_bf16(dvacc[d][4 * g4 + 2], dvacc[d][4 * g4 + 3]);
+                            *reinterpret_cast<uint2 *>(rk + d0) = pk;
+                            *reinterpret_cast<uint2 *>(rv + d0) = pv;
+                        } else {
+                            *reinterpret_cast<float4 *>(rk + d0) = make_float4(dkacc[d][4 * g4 + 0] * ksc, dkacc[d][4 * g4 + 1] * ksc,
+                                                                              dkacc[d][4 * g4 + 2] * ksc, dkacc[d][4 * g4 + 3] * ksc);
+                            *reinterpret_cast<float4 *>(rv + d0) = make_float4(dvacc[d][4 * g4 + 0], dvacc[d][4 * g4 + 1], dvacc[d][4 * g4 + 2], dvacc[d][4 * g4 + 3]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (d0 + e < dh) {
+                            DT<T>::st(rk + d0 + e, dkacc[d][4 * g4 + e] * ksc);
+                            DT<T>::st(rv + d0 + e, dvacc[d][4 * g4 + e]);
+                        }
                 }
             }
     }
 }
 
 template <typename T, int DHP>
-int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, hipStream_t st) {
+int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, bool pre, hipStream_t st) {
     constexpr int ES = sizeof(T), EPC = 16 / ES;
     const bool fast = (a.dh % EPC == 0) && (a.ldq % EPC == 0) && (a.ldk % EPC == 0) && (a.ldv % EPC == 0) && (a.lddo % EPC == 0) && (a.ldo % EPC == 0) &&
-                      aligned16(a.q) && aligned16(a.k) && aligned16(a.v) && aligned16(a.dout) && aligned16(a.o);
+                      aligned16(a.q) && aligned16(a.k) && aligned16(a.v) && aligned16(a.dout) && aligned16(a.o) &&
+                      (a.lddq % EPC == 0) && (a.lddk % EPC == 0) && (a.lddv % EPC == 0) && aligned16(a.dq) && aligned16(a.dk) && aligned16(a.dv);   // vector stores of the gradients too
     constexpr int RP = TileLayout<ES, DHP>::PITCH;
     const size_t lds_dq = 2 * (2 * TT * RP), lds_dkv = 2 * (2 * TT * RP + 2 * TT * sizeof(float));   // two stages each
-    auto launch_pair = [&](auto drop, auto fst) {
-        constexpr bool D = decltype(drop)::value, F = decltype(fst)::value;
+    if (pre && !fast) return acai_set_err(-1, "acai_attn_varlen_bwd: q_prescaled needs 16-byte aligned operands and d_h %% %d == 0", EPC);
+    auto launch_pair = [&](auto drop, auto fst, auto pr) {
+        constexpr bool D = decltype(drop)::value, F = decltype(fst)::value, P = decltype(pr)::value;
         static bool attr = false;  // one flag per instantiation
         if (!attr) {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_kernel<T, DHP, F, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_kernel<T, DHP, F, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_kernel<T, DHP, F, D, P>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_kernel<T, DHP, F, D, P>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             attr = true;
         }
         dim3 gq(cdiv(max_q, OB), a.H, B), gk(cdiv(max_k, OB), a.H, B);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DHP, F, D>), gq, dim3(256), lds_dq, st, a);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DHP, F, D>), gk, dim3(256), lds_dkv, st, a);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DHP, F, D, P>), gq, dim3(256), lds_dq, st, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DHP, F, D, P>), gk, dim3(256), lds_dkv, st, a);
     };
-    if (a.drop_thr) {
-        if (fast) launch_pair(std::true_type{}, std::true_type{});
-        else launch_pair(std::true_type{}, std::false_type{});
+    if (pre) {
+        if (a.drop_thr) launch_pair(std::true_type{}, std::true_type{}, std::true_type{});
+        else launch_pair(std::false_type{}, std::true_type{}, std::true_type{});
+    } else if (a.drop_thr) {
+        if (fast) launch_pair(std::true_type{}, std::true_type{}, std::false_type{});
+        else launch_pair(std::true_type{}, std::false_type{}, std::false_type{});
     } else {
-        if (fast) launch_pair(std::false_type{}, std::true_type{});
-        else launch_pair(std::false_type{}, std::false_type{});
+        if (fast) launch_pair(std::false_type{}, std::true_type{}, std::false_type{});
+        else launch_pair(std::false_type{}, std::false_type{}, std::false_type{});
     }
     ACAI_LAUNCH_CHECK("acai_attn_varlen_bwd");
     return 0;
@@ -481,7 +614,7 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, hipStream_t st) {
 extern "C" int acai_attn_varlen_bwd(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, const void *o, int ldo,
                                     const void *dout, int lddo, void *dq, int lddq, void *dk, int lddk, void *dv, int lddv, const float *lse,
                                     float *delta, const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int max_k,
-                                    int total_q, int causal, int dtype, float dropout_p, uint32_t dropout_seed, void *stream) {
+                                    int total_q, int causal, int dtype, float dropout_p, uint32_t dropout_seed, int q_prescaled, void *stream) {
     ACAI_CHECK_ARG(q && k && v && o && dout && dq && dk && dv && lse && delta && cu_q && cu_k, "acai_attn_varlen_bwd: null operand");
     ACAI_CHECK_ARG(B > 0 && H > 0 && dh > 0 && dh <= 64 && max_q > 0 && max_k > 0 && total_q > 0 && B <= 65535 && H <= 65535,
                    "acai_attn_varlen_bwd: bad dims");
@@ -494,7 +627,8 @@ extern "C" int acai_attn_varlen_bwd(const void *q, int ldq, const void *k, int l
     a.scale = 1.0f / sqrtf((float)dh);
     a.scale_log2e = 1.4426950408889634f * a.scale;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == ACAI_BF16) return dh <= 32 ? launch_bwd<bf16_t, 32>(a, B, max_q, max_k, st) : launch_bwd<bf16_t, 64>(a, B, max_q, max_k, st);
-    if (dtype == ACAI_F32) return dh <= 32 ? launch_bwd<float, 32>(a, B, max_q, max_k, st) : launch_bwd<float, 64>(a, B, max_q, max_k, st);
+    const bool pre = q_prescaled != 0;
+    if (dtype == ACAI_BF16) return dh <= 32 ? launch_bwd<bf16_t, 32>(a, B, max_q, max_k, pre, st) : launch_bwd<bf16_t, 64>(a, B, max_q, max_k, pre, st);
+    if (dtype == ACAI_F32) return dh <= 32 ? launch_bwd<float, 32>(a, B, max_q, max_k, pre, st) : launch_bwd<float, 64>(a, B, max_q, max_k, pre, st);
     return acai_set_err(-1, "acai_attn_varlen_bwd: bad dtype %d", dtype);
 }

@@ -33,7 +33,7 @@ struct AttnArgs {
     int total_q;
 };
 
-template <typename T, int DHP, bool FAST, bool DROP>
+template <typename T, int DHP, bool FAST, bool DROP, bool PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_fwd_kernel(AttnArgs a) {
     constexpr int ES = sizeof(T);
     constexpr int EPC = 16 / ES;                 // elements per 16-byte chunk
@@ -59,6 +59,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     const T *V = reinterpret_cast<const T *>(a.v) + (size_t)k_start * a.ldv + h * a.dh;
     T *O = reinterpret_cast<T *>(a.out) + (size_t)q_start * a.ldo + h * a.dh;
     const int dh = a.dh;
+    // PRE: q arrives multiplied by log2(e) / sqrt(d_h) (the in-projection's epilogue did it before the one rounding), so K . Q^T already is the
+    // score in the log2 domain and no per-score multiply is left
+    const float c = PRE ? 1.0f : a.scale_log2e;
 
     auto load16 = [&](const T *base, int ld, int row, int rows, int d0) -> uint4 {
         uint4 r = make_uint4(0, 0, 0, 0);
@@ -87,14 +90,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     for (int d = 0; d < NDB; ++d)
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
-    float m_run = -1.0e30f, l_run = 0.f;  // running max (scaled, log2 domain) and this lane-half's partial sum
-    // Row sums stay on the VALU.  Measured alternative (kept behind MFMA_SUM): one extra MFMA per 16 keys with an all-ones A operand
-    // replaces the 32 adds per tile, but the kernel got 20 % SLOWER (2.0 -> 2.46 ms at d_h = 32): the four dependent MFMAs per tile on one
-    // accumulator hold the wave's issue port longer than the adds they replace.
-    constexpr bool MFMA_SUM = false;
-    f32x16 lacc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
+    float m_run = -1.0e30f, l_run = 0.f;  // reference maximum (log2 domain) and this lane-half's partial row sum
+    // Row sums stay on the VALU.  Measured alternative: one extra MFMA per 16 keys with an all-ones A operand replaces the 32 adds per tile,
+    // but the kernel got 20 % SLOWER (2.0 -> 2.46 ms at d_h = 32): the four dependent MFMAs per tile on one accumulator hold the wave's
+    // issue port longer than the adds they replace.
 
     int nkt = (lk + KT - 1) / KT;
     if (a.causal) {
@@ -102,20 +101,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         nkt = min(nkt, last_q / KT + 1);
     }
 
-    // staging: thread -> NCH 16-byte chunks of the K and of the V tile; global pointers advance by one tile per iteration
+    // staging: thread -> NCH 16-byte chunks of the K and of the V tile; global pointers advance by one tile per call
     uint4 rk[NCH], rv[NCH];
     const T *kp[NCH], *vp[NCH];
     int srow[NCH], soff[NCH];
     bool dok[NCH];
+    auto stage_at = [&](int tile) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = tid + 256 * i, row = c / CPR, cc = c % CPR;
-        srow[i] = row;
-        soff[i] = TL::off(row, cc);
-        dok[i] = cc * EPC < dh;
-        kp[i] = K + (size_t)row * a.ldk + cc * EPC;
-        vp[i] = V + (size_t)row * a.ldv + cc * EPC;
-    }
+        for (int i = 0; i < NCH; ++i) {
+            const int cidx = tid + 256 * i, row = cidx / CPR, cc = cidx % CPR;
+            srow[i] = row;
+            soff[i] = TL::off(row, cc);
+            dok[i] = cc * EPC < dh;
+            kp[i] = K + ((size_t)tile * KT + row) * a.ldk + cc * EPC;
+            vp[i] = V + ((size_t)tile * KT + row) * a.ldv + cc * EPC;
+        }
+    };
     auto load_tile = [&](int kt) {
         if constexpr (FAST) {
             const bool full = (kt + 1) * KT <= lk;  // wave-uniform: interior tiles load unguarded
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         } else {
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
-                const int c = tid + 256 * i, d0 = (c % CPR) * EPC;
+                const int cidx = tid + 256 * i, d0 = (cidx % CPR) * EPC;
                 rk[i] = load16(K, a.ldk, kt * KT + srow[i], lk, d0);
                 rv[i] = load16(V, a.ldv, kt * KT + srow[i], lk, d0);
             }
@@ -147,20 +148,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         }
     };
 
-    load_tile(0);
-    store_tile(lds);
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const unsigned char *ldsK = lds + (kt & 1) * STAGE, *ldsV = ldsK + KT * KPITCH;
-        if (kt + 1 < nkt) load_tile(kt + 1);
-        // ---- S^T = K . Q^T : two 32-key blocks ---------------------------------------------------------
-        f32x16 sacc[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
-        // d-slice outer, key block inner: consecutive MFMAs alternate between the two accumulators (a chain of NS dependent MFMAs on
-        // one accumulator waits out the full MFMA latency at every link)
+    // S^T += K . Q^T of the two 32-key blocks of a tile, on top of whatever `sacc` holds.  d-slice outer, key block inner: consecutive MFMAs
+    // alternate between the two accumulators (a chain of NS dependent MFMAs on one accumulator waits out the full MFMA latency at every link)
+    auto qk = [&](f32x16 (&sacc)[2], const unsigned char *ldsK) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
 #pragma unroll
@@ -176,71 +166,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                 }
             }
         }
-
-        // ---- mask + online softmax (per-lane query) ----------------------------------------------------
-        // At d_h <= 64 this VALU block, not the MFMAs, bounds the kernel: interior tiles (every key valid for every query of the
-        // wave) take a path without compares / selects: 1 max + 1 fma + 1 exp2 + 1 add per score.
-        const int key_lim = a.causal ? min(lk, my_q + 1) : lk;  // keys < key_lim are attended
-        const int wave_lim = a.causal ? min(lk, q0 + wave * 32 + 1) : lk;  // keys < wave_lim are valid for ALL lanes of the wave
-        // Lazy rescale: the running maximum is only raised (and O, l rescaled) when some lane's tile maximum exceeds it by more than 2^8;
-        // otherwise probabilities are taken against the stale maximum (p <= 256: exact in the final O / l ratio up to rounding).
-        float psum = 0.f, m_new;
-        auto raise_max = [&](float tmax) {
-            if (__builtin_amdgcn_ballot_w64(tmax > m_run + 8.0f) != 0) {  // wave-uniform
-                const float m2 = fmaxf(m_run, tmax);
-                const float alpha = fast_exp2(m_run - m2);
-                m_run = m2;
-                l_run *= alpha;
-                lacc[0] *= alpha;
-#pragma unroll
-                for (int d = 0; d < NDB; ++d)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
-            }
-            return m_run;
-        };
-        if ((kt + 1) * KT <= wave_lim) {
-            float tmax = -1.0e30f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[kb][e]);
-            tmax *= a.scale_log2e;
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            m_new = raise_max(tmax);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float p = fast_exp2(fmaf(sacc[kb][e], a.scale_log2e, -m_new));
-                    sacc[kb][e] = p;
-                    if constexpr (!MFMA_SUM) psum += p;
-                }
-        } else {
-            float tmax = -1.0e30f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int key = kt * KT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    const float sv = key < key_lim ? sacc[kb][e] * a.scale_log2e : -1.0e30f;
-                    sacc[kb][e] = sv;
-                    tmax = fmaxf(tmax, sv);
-                }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            m_new = raise_max(tmax);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    // masked entries: gate on the mask value itself (a fully masked row keeps m = -1e30 and exp2(0) = 1 would be wrong)
-                    const float p = sacc[kb][e] > -0.5e30f ? fast_exp2(sacc[kb][e] - m_new) : 0.f;
-                    sacc[kb][e] = p;
-                    if constexpr (!MFMA_SUM) psum += p;
-                }
-        }
-        l_run += psum;
-        if constexpr (DROP) {  // the normaliser uses the undropped probabilities; only the P that multiplies V is masked and rescaled
+    };
+    // O^T += V^T . P^T with P taken straight from the score accumulators (dropout, if any, masks the P that multiplies V only: the
+    // normaliser uses the undropped probabilities)
+    auto pv = [&](f32x16 (&sacc)[2], const unsigned char *ldsV, int kt) {
+        if constexpr (DROP) {
             const uint32_t rrow = (uint32_t)(h * a.total_q + q_start + my_q);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -250,7 +180,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                     sacc[kb][e] = drop_keep(a.drop_seed, rrow, key, a.drop_thr) ? sacc[kb][e] * a.drop_scale : 0.f;
                 }
         }
-        // ---- O^T += V^T . P^T --------------------------------------------------------------------------
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             if constexpr (ES == 2) {
@@ -261,10 +190,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                     pf.y = pack_bf16(sacc[kb][8 * s2 + 2], sacc[kb][8 * s2 + 3]);
                     pf.z = pack_bf16(sacc[kb][8 * s2 + 4], sacc[kb][8 * s2 + 5]);
                     pf.w = pack_bf16(sacc[kb][8 * s2 + 6], sacc[kb][8 * s2 + 7]);
-                    if constexpr (MFMA_SUM) {
-                        const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);  // bf16 1.0 x 8
-                        lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf), lacc, 0, 0, 0);
-                    }
 #pragma unroll
                     for (int d = 0; d < NDB; ++d) {
                         // A element j = V[key 16 s2 + 8 (j>>2) + 4 lh + (j&3)][d]: two 4-key x 16-d transposing reads of the natural V tile
@@ -294,13 +219,155 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                 }
             }
         }
+    };
+
+    stage_at(0);
+    load_tile(0);
+    store_tile(lds);
+    __syncthreads();
+
+    // ---- fast loop: the leading tiles whose every key is attended by every query of the WORKGROUP -------------------------------------
+    // At d_h <= 64 the VALU issue port, not the MFMA, bounds this kernel (PMC: 85 % of the SIMD cycles issue, 22 % of them MFMA), so the
+    // common tile carries nothing but 1 exp2 + 1 add per score and one bf16 pack per two (PRE) - no maximum, no rescale, no compare:
+    //   * the reference maximum is the row maximum of tile 0, taken once in front of the loop;
+    //   * PRE: the score accumulators START at -m, so the MFMA leaves (score - m) and the exponential reads it directly;
+    //   * fp32 holds 2^(score - m) until score - m reaches 2^7: a row sum above 2^80 (or inf / NaN) sets `bad`, and a workgroup with a bad
+    //     lane starts over in the general loop below, which keeps a running maximum.  (LayerNorm-ed activations never come near; the
+    //     general loop is also what the masked tiles take.)
+    // Keeping the rescale out of this loop matters beyond the compare: as `if (raise) O *= alpha` in front of the P.V MFMAs it made the
+    // compiler keep two copies of O (16 v_mov_b64 per tile behind an s_nop that waits out the last MFMA).
+    int n_fast = min(nkt, (a.causal ? min(lk, q0 + 1) : lk) / KT);
+    bool bad = false;
+    if (n_fast > 0) {
+        f32x16 s0[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s0[kb][e] = 0.f;
+        qk(s0, lds);
+        float tmax = -1.0e30f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, s0[kb][e]);
+        tmax *= c;
+        m_run = fmaxf(tmax, __shfl_xor(tmax, 32));
+    }
+    f32x16 minit;   // PRE: start value of the score accumulators
+#pragma unroll
+    for (int e = 0; e < 16; ++e) minit[e] = PRE ? -m_run : 0.f;
+    for (int kt = 0; kt < n_fast; ++kt) {
+        const unsigned char *ldsK = lds + (kt & 1) * STAGE, *ldsV = ldsK + KT * KPITCH;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        f32x16 sacc[2] = {minit, minit};
+        qk(sacc, ldsK);
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = PRE ? fast_exp2(sacc[kb][e]) : fast_exp2(fmaf(sacc[kb][e], c, -m_run));
+                sacc[kb][e] = p;
+                psum += p;
+            }
+        bad |= !(psum < 1.2e24f);   // 2^80; also true for inf and NaN
+        l_run += psum;
+        pv(sacc, ldsV, kt);
+        if (kt + 1 < nkt) store_tile(lds + ((kt + 1) & 1) * STAGE);
+        __syncthreads();   // one barrier per tile: stage (kt+1)&1 was last read in iteration kt-1
+    }
+    int kt0 = n_fast;
+    if (n_fast > 0 && __syncthreads_or(bad)) {   // start over with a running maximum (all waves: the barrier count must match)
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+        m_run = -1.0e30f;
+        l_run = 0.f;
+        kt0 = 0;
+        stage_at(0);
+        load_tile(0);
+        store_tile(lds);
+        __syncthreads();
+    }
+
+    // ---- general loop: masked tiles (ragged end, causal diagonal) and restarted workgroups: online softmax with a running maximum ------
+    for (int kt = kt0; kt < nkt; ++kt) {
+        const unsigned char *ldsK = lds + (kt & 1) * STAGE, *ldsV = ldsK + KT * KPITCH;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
+        qk(sacc, ldsK);
+
+        // ---- mask + online softmax (per-lane query) ----------------------------------------------------
+        const int key_lim = a.causal ? min(lk, my_q + 1) : lk;  // keys < key_lim are attended
+        const int wave_lim = a.causal ? min(lk, q0 + wave * 32 + 1) : lk;  // keys < wave_lim are valid for ALL lanes of the wave
+        // Lazy rescale: the running maximum is only raised (and O, l rescaled) when some lane's tile maximum exceeds it by more than 2^8;
+        // otherwise probabilities are taken against the stale maximum (p <= 256: exact in the final O / l ratio up to rounding).
+        auto raise_max = [&](float tmax) {
+            if (__builtin_amdgcn_ballot_w64(tmax > m_run + 8.0f) != 0) {  // wave-uniform
+                const float m2 = fmaxf(m_run, tmax);
+                const float alpha = fast_exp2(m_run - m2);
+                m_run = m2;
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+            }
+        };
+        float psum = 0.f;
+        if ((kt + 1) * KT <= wave_lim) {
+            float tmax = -1.0e30f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[kb][e]);
+            tmax *= c;
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            raise_max(tmax);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float p = fast_exp2(fmaf(sacc[kb][e], c, -m_run));
+                    sacc[kb][e] = p;
+                    psum += p;
+                }
+        } else {
+            float tmax = -1.0e30f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kt * KT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const float sv = key < key_lim ? sacc[kb][e] * c : -1.0e30f;
+                    sacc[kb][e] = sv;
+                    tmax = fmaxf(tmax, sv);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            raise_max(tmax);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    // masked entries: gate on the mask value itself (a fully masked row keeps m = -1e30 and exp2(0) = 1 would be wrong)
+                    const float p = sacc[kb][e] > -0.5e30f ? fast_exp2(sacc[kb][e] - m_run) : 0.f;
+                    sacc[kb][e] = p;
+                    psum += p;
+                }
+        }
+        l_run += psum;
+        pv(sacc, ldsV, kt);
         if (kt + 1 < nkt) store_tile(lds + ((kt + 1) & 1) * STAGE);
         __syncthreads();   // one barrier per tile: stage (kt+1)&1 was last read in iteration kt-1
     }
 
     // ---- normalise and store: lane owns query my_q, registers hold d = db*32 + (e&3) + 8*(e>>2) + 4*lh ------
-    // MFMA row sums: every lane of a column holds the complete sum over all keys (both lane halves)
-    const float l_tot = MFMA_SUM ? lacc[0] : l_run + __shfl_xor(l_run, 32);
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (a.lse && my_q < lq && lh == 0) a.lse[(size_t)h * a.total_q + q_start + my_q] = m_run + log2f(l_tot);
     if (my_q < lq) {
@@ -333,29 +400,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 }
 
 template <typename T, int DHP>
-int launch(const AttnArgs &a, int B, int max_q, hipStream_t st) {
+int launch(const AttnArgs &a, int B, int max_q, bool pre, hipStream_t st) {
     constexpr int EPC = 16 / sizeof(T);
     const bool fast = (a.dh % EPC == 0) && (a.ldq % EPC == 0) && (a.ldk % EPC == 0) && (a.ldv % EPC == 0) && (a.ldo % EPC == 0) &&
                       aligned16(a.q) && aligned16(a.k) && aligned16(a.v) && aligned16(a.out);
     dim3 grid(cdiv(max_q, QB), a.H, B);
-    if (a.drop_thr) {  // train-mode attention dropout: its own instantiation, so the common kernel carries no hash code / registers
-        if (fast)
-            hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, true, true>), grid, dim3(256), 0, st, a);
+    // train-mode attention dropout is its own instantiation, so the common kernel carries no hash code / registers; the prescaled-q form
+    // (training path) exists for 16-byte-aligned operands only
+    if (pre) {
+        if (!fast) return acai_set_err(-1, "acai_attn_varlen_fwd: q_prescaled needs 16-byte aligned operands and d_h %% %d == 0", EPC);
+        if (a.drop_thr)
+            hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, true, true, true>), grid, dim3(256), 0, st, a);
         else
-            hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, false, true>), grid, dim3(256), 0, st, a);
+            hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, true, false, true>), grid, dim3(256), 0, st, a);
+    } else if (a.drop_thr) {
+        if (fast)
+            hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, true, true, false>), grid, dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, false, true, false>), grid, dim3(256), 0, st, a);
     } else if (fast)
-        hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, true, false>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, true, false, false>), grid, dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, false, false>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, false, false, false>), grid, dim3(256), 0, st, a);
     ACAI_LAUNCH_CHECK("acai_attn_varlen_fwd");
     return 0;
 }
 
 }  // namespace
 
+// q_prescaled: q already carries the factor log2(e) / sqrt(dh) (acai_gemm_nt_ex's column scale on the in-projection); the kernel then
+// takes K . Q^T as the score in the log2 domain.  `lse` has the same meaning either way.
 extern "C" int acai_attn_varlen_fwd(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, void *out, int ldo,
                                     const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int causal,
-                                    int dtype, float *lse, int total_q, float dropout_p, uint32_t dropout_seed, void *stream) {
+                                    int dtype, float *lse, int total_q, float dropout_p, uint32_t dropout_seed, int q_prescaled, void *stream) {
     ACAI_CHECK_ARG(q && k && v && out && cu_q && cu_k, "acai_attn_varlen_fwd: null operand");
     ACAI_CHECK_ARG(B > 0 && H > 0 && dh > 0 && dh <= 64 && max_q > 0, "acai_attn_varlen_fwd: bad dims B=%d H=%d dh=%d max_q=%d (dh <= 64)", B, H, dh, max_q);
     ACAI_CHECK_ARG(ldq >= H * dh && ldk >= H * dh && ldv >= H * dh && ldo >= H * dh, "acai_attn_varlen_fwd: row stride smaller than H*dh");
@@ -365,7 +442,8 @@ extern "C" int acai_attn_varlen_fwd(const void *q, int ldq, const void *k, int l
                1.0f / (1.0f - dropout_p), lse, total_q};
     a.scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == ACAI_BF16) return dh <= 32 ? launch<bf16_t, 32>(a, B, max_q, st) : launch<bf16_t, 64>(a, B, max_q, st);
-    if (dtype == ACAI_F32) return dh <= 32 ? launch<float, 32>(a, B, max_q, st) : launch<float, 64>(a, B, max_q, st);
+    const bool pre = q_prescaled != 0;
+    if (dtype == ACAI_BF16) return dh <= 32 ? launch<bf16_t, 32>(a, B, max_q, pre, st) : launch<bf16_t, 64>(a, B, max_q, pre, st);
+    if (dtype == ACAI_F32) return dh <= 32 ? launch<float, 32>(a, B, max_q, pre, st) : launch<float, 64>(a, B, max_q, pre, st);
     return acai_set_err(-1, "acai_attn_varlen_fwd: bad dtype %d", dtype);
 }

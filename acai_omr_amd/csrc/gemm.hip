@@ -30,6 +30,9 @@ struct GemmArgs {
     // aux_mode 2: C = round(acc) * gelu'(aux)  (the dX GEMM of linear2 applies the GELU derivative of the saved pre-activation)
     void *aux;
     int ldaux, aux_mode;
+    // columns [0, scale_cols) of (A.W^T + bias) are multiplied by col_scale before rounding (the in-projection's q for the attention kernels)
+    int scale_cols;
+    float col_scale;
     // EPI == 1 (cross K/V prefill scatter)
     const int32_t *row_seq, *row_pos, *seq_len;
     const int64_t *seq_off;
@@ -65,6 +68,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&
         const int col = bn0 + wn * 64 + j * 32 + lr;
         if (col >= g.N) continue;
         const float bv = g.bias ? g.bias[col] : 0.f;
+        const float cs = col < g.scale_cols ? g.col_scale : 1.0f;
         int kv = 0, hh = 0, dd = 0;
         if constexpr (EPI == 1) {
             kv = col / g.E;
@@ -80,6 +84,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&
                 if (row >= g.M) continue;
                 float v = acc[i][j][e] + bv;
                 if constexpr (EPI == 0) {
+                    v *= cs;
                     if (do_round) v = round_bf16(v);
                     if (g.aux_mode == 1) {
                         if (g.out_dtype == ACAI_BF16) reinterpret_cast<bf16_t *>(g.aux)[(size_t)row * g.ldaux + col] = f2bf(v);
@@ -335,10 +340,11 @@ __device__ __forceinline__ void gemm_vec_epilogue(const GemmArgs &g, const f32x1
         for (int j = 0; j < 2; ++j) {
             const int col = bn0 + wn * 64 + j * 32 + lr;
             const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+            const float cs = col < g.scale_cols ? g.col_scale : 1.0f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 if (NP == 2 && (e >> 3) != pass) continue;   // 16-row passes: registers 0..7 hold rows 0..15, 8..15 rows 16..31
-                float v = acc[i][j][e] + bv;
+                float v = (acc[i][j][e] + bv) * cs;
                 if (pre_round) v = round_bf16(v);
                 stg[((e & 3) + 8 * ((e >> 2) & (NP == 2 ? 1 : 3)) + 4 * lh) * EP + j * 32 + lr] = v;
             }
@@ -1227,7 +1233,7 @@ extern "C" int acai_gemm_set_variant(int variant) {
 
 extern "C" int acai_gemm_nt_ex(const void *A, int lda, const void *W, int ldw, const float *bias, const float *residual, int ldr,
                                void *C, int ldc, void *aux, int ldaux, int aux_mode, int M, int N, int K, int in_dtype, int out_dtype, int flags,
-                               void *stream) {
+                               int scale_cols, float col_scale, void *stream) {
     ACAI_CHECK_ARG(A && W && C, "acai_gemm_nt: null operand");
     ACAI_CHECK_ARG(M >= 0 && N > 0 && K > 0, "acai_gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
     ACAI_CHECK_ARG(lda >= K && ldw >= K && ldc >= N && (!residual || ldr >= N), "acai_gemm_nt: leading dimension smaller than row");
@@ -1242,12 +1248,14 @@ extern "C" int acai_gemm_nt_ex(const void *A, int lda, const void *W, int ldw, c
     g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.out_dtype = out_dtype; g.flags = flags;
     g.aux = aux; g.ldaux = ldaux; g.aux_mode = aux_mode;
+    ACAI_CHECK_ARG(scale_cols >= 0 && scale_cols <= N, "acai_gemm_nt_ex: scale_cols %d outside [0, N]", scale_cols);
+    g.scale_cols = scale_cols; g.col_scale = col_scale;
     return in_dtype == ACAI_BF16 ? launch<bf16_t, 0>(g, (hipStream_t)stream) : launch<float, 0>(g, (hipStream_t)stream);
 }
 
 extern "C" int acai_gemm_nt(const void *A, int lda, const void *W, int ldw, const float *bias, const float *residual, int ldr,
                             void *C, int ldc, int M, int N, int K, int in_dtype, int out_dtype, int flags, void *stream) {
-    return acai_gemm_nt_ex(A, lda, W, ldw, bias, residual, ldr, C, ldc, nullptr, 0, 0, M, N, K, in_dtype, out_dtype, flags, stream);
+    return acai_gemm_nt_ex(A, lda, W, ldw, bias, residual, ldr, C, ldc, nullptr, 0, 0, M, N, K, in_dtype, out_dtype, flags, 0, 1.0f, stream);
 }
 
 // General form for the backward pass: C[M,N] = op(A) . op(W)^T (+bias) (+residual), logical A [M,K], logical W [N,K];

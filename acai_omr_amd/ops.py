@@ -6,6 +6,8 @@ faulting kernel can take the whole node down) and raises RuntimeError on a non-z
 """
 import functools
 
+import math
+
 import torch
 
 from . import _lib
@@ -77,10 +79,12 @@ def layernorm(x, w, b, eps, want_f32=True, want_bf16=False, out_f32=None):
     return y32, y16
 
 
-def gemm_nt(a, w, bias=None, residual=None, out_dtype=torch.float32, gelu=False, round_bf16=False, out=None, pre_act=None, gelu_grad_of=None):
+def gemm_nt(a, w, bias=None, residual=None, out_dtype=torch.float32, gelu=False, round_bf16=False, out=None, pre_act=None, gelu_grad_of=None,
+            col_scale=None):
     """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias) (+ residual).  a, w share a dtype (fp32 or bf16); 2-D, row stride free.
     pre_act (with gelu): [M,N] tensor of out's dtype that receives the pre-activation; gelu_grad_of: [M,N] saved pre-activation whose GELU
-    derivative multiplies the (rounded) product."""
+    derivative multiplies the (rounded) product; col_scale = (n, s): columns [0, n) of (a @ w^T + bias) are multiplied by s before rounding
+    (the in-projection hands q to the attention kernels as q * log2(e) / sqrt(dh), see attn_varlen(q_prescaled=True))."""
     _chk(a, "a"), _chk(w, "w")
     assert a.dim() == 2 and w.dim() == 2 and a.dtype == w.dtype and a.shape[1] == w.shape[1], (a.shape, w.shape, a.dtype, w.dtype)
     M, K = a.shape
@@ -94,12 +98,17 @@ def gemm_nt(a, w, bias=None, residual=None, out_dtype=torch.float32, gelu=False,
         assert residual.dtype == torch.float32 and residual.shape == (M, N) and residual.stride(1) == 1
     flags = (GEMM_GELU if gelu else 0) | (GEMM_ROUND_BF16 if round_bf16 else 0)
     aux = pre_act if pre_act is not None else gelu_grad_of
-    if aux is not None:
-        assert (pre_act is None) != (gelu_grad_of is None) and aux.shape == (M, N) and aux.dtype == out.dtype and aux.stride(1) == 1
-        assert (pre_act is None) or gelu
+    if aux is not None or col_scale is not None:
+        mode = 0
+        if aux is not None:
+            assert (pre_act is None) != (gelu_grad_of is None) and aux.shape == (M, N) and aux.dtype == out.dtype and aux.stride(1) == 1
+            assert (pre_act is None) or gelu
+            mode = 1 if pre_act is not None else 2
+        ncol, cs = col_scale if col_scale is not None else (0, 1.0)
         _lib.check(_lib.lib().acai_gemm_nt_ex(a.data_ptr(), _ld(a), w.data_ptr(), _ld(w), _p(bias), _p(residual),
-                                              _ld(residual) if residual is not None else 0, out.data_ptr(), _ld(out), aux.data_ptr(), _ld(aux),
-                                              1 if pre_act is not None else 2, M, N, K, _dt(a), _dt(out), flags, _st()), "acai_gemm_nt_ex")
+                                              _ld(residual) if residual is not None else 0, out.data_ptr(), _ld(out),
+                                              aux.data_ptr() if aux is not None else None, _ld(aux) if aux is not None else 0,
+                                              mode, M, N, K, _dt(a), _dt(out), flags, int(ncol), float(cs), _st()), "acai_gemm_nt_ex")
         return out
     _lib.check(_lib.lib().acai_gemm_nt(a.data_ptr(), _ld(a), w.data_ptr(), _ld(w), _p(bias), _p(residual),
                                        _ld(residual) if residual is not None else 0, out.data_ptr(), _ld(out),
@@ -198,8 +207,14 @@ def gather_rows(table, idx, add=None, out=None):
     return out
 
 
-def attn_varlen(q, k, v, cu_q, cu_k, H, dh, max_q, causal=False, out=None, lse=None, dropout_p=0.0, seed=0):
-    """q [Mq, >=H*dh], k/v [Mk, >=H*dh] (2-D views with any row stride), cu_* int32 [B+1] on the GPU."""
+def QSCALE(dh):
+    """The factor a prescaled q carries: the softmax scale in the log2 domain."""
+    return 1.4426950408889634 / math.sqrt(dh)
+
+
+def attn_varlen(q, k, v, cu_q, cu_k, H, dh, max_q, causal=False, out=None, lse=None, dropout_p=0.0, seed=0, q_prescaled=False):
+    """q [Mq, >=H*dh], k/v [Mk, >=H*dh] (2-D views with any row stride), cu_* int32 [B+1] on the GPU.
+    q_prescaled: q already carries log2(e) / sqrt(dh) (QSCALE(dh); gemm_nt(col_scale=...) on the in-projection)."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _chk(t, n)
         assert t.dim() == 2 and t.dtype == q.dtype
@@ -211,7 +226,8 @@ def attn_varlen(q, k, v, cu_q, cu_k, H, dh, max_q, causal=False, out=None, lse=N
     assert out.shape[0] == q.shape[0] and out.stride(1) == 1 and out.dtype == q.dtype
     _lib.check(_lib.lib().acai_attn_varlen_fwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
                                                out.data_ptr(), out.stride(0), cu_q.data_ptr(), cu_k.data_ptr(), B, H, dh, int(max_q),
-                                               1 if causal else 0, _dt(q), _p(lse), q.shape[0], float(dropout_p), int(seed) & 0xFFFFFFFF, _st()),
+                                               1 if causal else 0, _dt(q), _p(lse), q.shape[0], float(dropout_p), int(seed) & 0xFFFFFFFF,
+                                               1 if q_prescaled else 0, _st()),
                "acai_attn_varlen_fwd")
     return out
 
@@ -274,8 +290,9 @@ def decode_attn(q, kc, vc, seq_off, seq_len, H, dh, dhp, max_len, round_out=Fals
     return out
 
 
-def attn_varlen_bwd(q, k, v, o, dout, lse, cu_q, cu_k, H, dh, max_q, max_k, causal, dq, dk, dv, dropout_p=0.0, seed=0):
-    """Gradients of attn_varlen w.r.t. q, k, v, written into the (strided) views dq, dk, dv."""
+def attn_varlen_bwd(q, k, v, o, dout, lse, cu_q, cu_k, H, dh, max_q, max_k, causal, dq, dk, dv, dropout_p=0.0, seed=0, q_prescaled=False):
+    """Gradients of attn_varlen w.r.t. q, k, v, written into the (strided) views dq, dk, dv.  q_prescaled: q is the forward's prescaled
+    q; dq is still the gradient w.r.t. the unscaled in-projection output."""
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (dout, "dout"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
         _chk(t, n)
         assert t.dim() == 2 and t.dtype == q.dtype, n
@@ -287,7 +304,8 @@ def attn_varlen_bwd(q, k, v, o, dout, lse, cu_q, cu_k, H, dh, max_q, max_k, caus
     _lib.check(_lib.lib().acai_attn_varlen_bwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), o.data_ptr(), o.stride(0),
                                                dout.data_ptr(), dout.stride(0), dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(),
                                                dv.stride(0), lse.data_ptr(), delta.data_ptr(), cu_q.data_ptr(), cu_k.data_ptr(), B, H, dh, int(max_q),
-                                               int(max_k), total_q, 1 if causal else 0, _dt(q), float(dropout_p), int(seed) & 0xFFFFFFFF, _st()),
+                                               int(max_k), total_q, 1 if causal else 0, _dt(q), float(dropout_p), int(seed) & 0xFFFFFFFF,
+                                               1 if q_prescaled else 0, _st()),
                "acai_attn_varlen_bwd")
 
 

@@ -186,18 +186,21 @@ class SelfAttnBlockFn(Function):
         E = x32.shape[1]
         dh = E // H
         x = _compute_copy(x32, prec)
-        qkv = ops.gemm_nt(x, wc.w(Wi, prec), wc.b(bi, prec), out_dtype=cdt, round_bf16=bf)
+        # the in-projection's epilogue hands q over as q * log2(e) / sqrt(dh) (one rounding, after the scale - torch's math SDPA scales q
+        # before the product too): the attention kernels then spend no multiply per score.  The saved qkv holds that q'.
+        pre = _QPRESCALE and bf and E % 8 == 0 and dh % 8 == 0
+        qkv = ops.gemm_nt(x, wc.w(Wi, prec), wc.b(bi, prec), out_dtype=cdt, round_bf16=bf, col_scale=(E, ops.QSCALE(dh)) if pre else None)
         lse = torch.empty(H * x.shape[0], dtype=torch.float32, device=x.device)
-        attn = ops.attn_varlen(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], cu, cu, H, dh, max_len, causal=causal, lse=lse)
+        attn = ops.attn_varlen(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], cu, cu, H, dh, max_len, causal=causal, lse=lse, q_prescaled=pre)
         y = ops.gemm_nt(attn, wc.w(Wo, prec), wc.b(bo, prec), residual=x32, out_dtype=torch.float32, round_bf16=bf)
         ctx.save_for_backward(x, qkv, attn, lse, cu, Wi, Wo)
-        ctx.cfg = (H, dh, max_len, causal, prec, wc)
+        ctx.cfg = (H, dh, max_len, causal, prec, wc, pre)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, qkv, attn, lse, cu, Wi, Wo = ctx.saved_tensors
-        H, dh, max_len, causal, prec, wc = ctx.cfg
+        H, dh, max_len, causal, prec, wc, pre = ctx.cfg
         bf = prec == "bf16"
         E = H * dh
         dy = dy.contiguous()
@@ -207,7 +210,7 @@ class SelfAttnBlockFn(Function):
         dbo = (cs if cs is not None else ops.colsum(dyc)) if ctx.needs_input_grad[4] else None
         dqkv = torch.empty_like(qkv)
         ops.attn_varlen_bwd(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], attn, dattn, lse, cu, cu, H, dh, max_len, max_len, causal,
-                            dqkv[:, :E], dqkv[:, E:2 * E], dqkv[:, 2 * E:])
+                            dqkv[:, :E], dqkv[:, E:2 * E], dqkv[:, 2 * E:], q_prescaled=pre)   # dq: w.r.t. the UNSCALED in-projection output
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_nt(dqkv, wc.wt(Wi, prec), residual=dy.float() if dy.dtype != torch.float32 else dy, out_dtype=torch.float32, round_bf16=bf)
@@ -217,6 +220,7 @@ class SelfAttnBlockFn(Function):
 
 
 _FUSED_MLP = os.environ.get("ACAI_FUSED_MLP", "1") != "0"   # A/B aid
+_QPRESCALE = os.environ.get("ACAI_QPRESCALE", "1") != "0"   # A/B aid: q leaves the in-projection already scaled for the attention kernels
 _LN_COLSUM = os.environ.get("ACAI_LN_COLSUM", "1") != "0"   # A/B aid: LayerNorm backward also forms the consuming Linear's bias gradient
 
 

@@ -47,10 +47,12 @@ int acai_gemm_nt(const void *A, int lda, const void *W, int ldw, const float *bi
 /* acai_gemm_nt with an auxiliary [M][N] operand of C's dtype (the MLP of nn.TransformerEncoderLayer / DecoderLayer in training:
  * linear1 -> GELU -> linear2, acai_omr/models/models.py:30-34,186-190,422-426 and their autograd):
  *   aux_mode 1 (with ACAI_GEMM_GELU): aux receives the pre-activation (bias added, bf16-rounded if asked), C its GELU - the forward keeps both;
- *   aux_mode 2: C = round(A.W^T) * gelu'(aux) - the dX GEMM of linear2 multiplies by the GELU derivative of the saved pre-activation. */
+ *   aux_mode 2: C = round(A.W^T) * gelu'(aux) - the dX GEMM of linear2 multiplies by the GELU derivative of the saved pre-activation.
+ * scale_cols > 0: columns [0, scale_cols) of (A.W^T + bias) are multiplied by col_scale before rounding - the in-projection of
+ * nn.MultiheadAttention hands q to the attention kernels as q * log2(e) / sqrt(dh) (acai_attn_varlen_fwd, q_prescaled). */
 int acai_gemm_nt_ex(const void *A, int lda, const void *W, int ldw, const float *bias, const float *residual, int ldr,
                     void *C, int ldc, void *aux, int ldaux, int aux_mode, int M, int N, int K, int in_dtype, int out_dtype, int flags,
-                    void *stream);
+                    int scale_cols, float col_scale, void *stream);
 /* Testing / tuning aid: pin the row-major GEMM kernel (0 auto; 1 128x128 two-stage; 2 256x128 two-stage; 3 256x128 three-stage; 4 256x128
  * persistent three-stage ring; 5 256x256 two-stage).  A pinned variant still falls back when the shape cannot use it.  No reference counterpart. */
 int acai_gemm_set_variant(int variant);
@@ -104,18 +106,23 @@ int acai_cast_f32_bf16(const float *x, void *y, int64_t n, void *stream);
  * causal != 0 applies the triu(diagonal=1) mask of M:468.  dh <= 64.
  * lse (optional, [H][total_q] fp32): log2-domain log-sum-exp of the scaled scores, saved for acai_attn_varlen_bwd.
  * dropout_p > 0: attention-probability dropout (nn.MultiheadAttention(dropout=p) in train mode); the keep mask is a counter-based
- * hash of (dropout_seed, head, query, key) that the backward regenerates. */
+ * hash of (dropout_seed, head, query, key) that the backward regenerates.
+ * q_prescaled != 0: q already carries the softmax scale in the log2 domain, q' = q * log2(e) / sqrt(dh) - applied by the in-projection's
+ * epilogue (acai_gemm_nt_ex scale_cols / col_scale) before its one rounding, as torch's math SDPA applies the scale to q before the
+ * product - so K . q' is the exponent itself and the kernel spends no multiply per score.  Needs 16-byte aligned operands. */
 int acai_attn_varlen_fwd(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, void *out, int ldo,
                          const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int causal,
-                         int dtype, float *lse, int total_q, float dropout_p, uint32_t dropout_seed, void *stream);
+                         int dtype, float *lse, int total_q, float dropout_p, uint32_t dropout_seed, int q_prescaled, void *stream);
 
 /* Backward of acai_attn_varlen_fwd (autograd of the same SDPA; training loops pre_train.py:59, omr_teacher_force_train.py:118).
  * o / lse are the forward's outputs, dout the incoming gradient; dq/dk/dv take the layout of q/k/v (own row strides).
- * delta: workspace [H][total_q] floats.  Deterministic (no atomics): S and P are recomputed per kernel. */
+ * delta: workspace [H][total_q] floats.  Deterministic (no atomics): S and P are recomputed per kernel.
+ * q_prescaled != 0: q is the forward's q' (see there); dq is still the gradient with respect to the UNSCALED in-projection output
+ * (what the in-projection's backward GEMMs consume), dk and dv are unchanged in meaning. */
 int acai_attn_varlen_bwd(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, const void *o, int ldo,
                          const void *dout, int lddo, void *dq, int lddq, void *dk, int lddk, void *dv, int lddv, const float *lse,
                          float *delta, const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int max_k,
-                         int total_q, int causal, int dtype, float dropout_p, uint32_t dropout_seed, void *stream);
+                         int total_q, int causal, int dtype, float dropout_p, uint32_t dropout_seed, int q_prescaled, void *stream);
 
 /* Backward of nn.LayerNorm: dx (fp32) from x, w, dy; dw/db (both or neither NULL) are ACCUMULATED with fp32 atomics (zero or seed
  * them); dx_bf16 (may be NULL; needs dim % 256 == 0, dim <= 1024): bf16 copy of dx for the GEMM that consumes it; dxsum (may be NULL, same

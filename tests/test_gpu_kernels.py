@@ -115,8 +115,12 @@ def ref_attn(q, k, v, lens_q, lens_k, H, dh, causal):
     (1, 10, [70], None, True),
 ])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_attn_varlen(dev, H, dh, lens_q, lens_k, causal, dtype):
+@pytest.mark.parametrize("prescaled", [False, True])
+def test_attn_varlen(dev, H, dh, lens_q, lens_k, causal, dtype, prescaled):
+    """prescaled: q carries log2(e)/sqrt(dh) (the training path's in-projection epilogue); the reference takes the same q, scaled back."""
     from acai_omr_amd import engine, ops
+    if prescaled and dh % (8 if dtype == "bf16" else 4):
+        pytest.skip("the prescaled form exists for 16-byte-aligned heads only")
     lens_k = lens_k or lens_q
     g = torch.Generator().manual_seed(H * dh + sum(lens_q))
     E = H * dh
@@ -127,11 +131,45 @@ def test_attn_varlen(dev, H, dh, lens_q, lens_k, causal, dtype):
         qkv, kv = rb(qkv), rb(kv)
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
     qd, kd = qkv.to(dev).to(tdt), kv.to(dev).to(tdt)
+    q_ref = qkv[:, :E]
+    if prescaled:
+        qp = (qkv[:, :E] * ops.QSCALE(dh)).to(tdt)
+        qd = torch.cat([qp.to(dev), qd[:, E:]], 1)
+        q_ref = qp.double() / ops.QSCALE(dh)
     cu_q, cu_k = engine.cu_from_lens(lens_q, dev), engine.cu_from_lens(lens_k, dev)
-    out = ops.attn_varlen(qd[:, :E], kd[:, E:2 * E], kd[:, 2 * E:], cu_q, cu_k, H, dh, max(lens_q), causal=causal)
-    ref = ref_attn(qkv[:, :E], kv[:, E:2 * E], kv[:, 2 * E:], lens_q, lens_k, H, dh, causal)
+    out = ops.attn_varlen(qd[:, :E], kd[:, E:2 * E], kd[:, 2 * E:], cu_q, cu_k, H, dh, max(lens_q), causal=causal, q_prescaled=prescaled)
+    ref = ref_attn(q_ref, kv[:, E:2 * E], kv[:, 2 * E:], lens_q, lens_k, H, dh, causal)
     err = (out.cpu().double() - ref).abs().max()
-    assert err < (2e-5 if dtype == "fp32" else 2e-2), err
+    # bf16: the output's own rounding is half an ulp = 2^-9 of its magnitude, P's is as much again
+    assert err < (2e-5 if dtype == "fp32" else 1.2e-2 * max(1.0, float(ref.abs().max()))), err
+
+
+@pytest.mark.parametrize("prescaled", [False, True])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_attn_varlen_reference_maximum_restart(dev, dtype, prescaled):
+    """The tiles in front of the ragged end take their reference maximum from tile 0 alone.  Scores that later rise past it by more than
+    2^80 (here: by ~130 in the log2 domain) overflow the row sum; the workgroup then starts over with a running maximum - same result."""
+    from acai_omr_amd import engine, ops
+    H, dh, lens = 2, 32, [320, 200]
+    E = H * dh
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(sum(lens), E, generator=g) * 0.1 + 4.0
+    k = torch.randn(sum(lens), E, generator=g) * 0.05
+    v = torch.randn(sum(lens), E, generator=g)
+    k[200] = 4.0          # sequence 0: one key 130 above everything before it, three tiles in
+    k[250, :dh] = -4.0    # and a very negative one for head 0
+    k[320 + 150] = 3.0    # sequence 1
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    q, k, v = (t.to(tdt).float() for t in (q, k, v))
+    qd = (q * ops.QSCALE(dh)).to(tdt) if prescaled else q.to(tdt)
+    q_ref = qd.double() / ops.QSCALE(dh) if prescaled else q
+    cu = engine.cu_from_lens(lens, dev)
+    lse = torch.empty(H * sum(lens), device=dev)
+    out = ops.attn_varlen(qd.to(dev), k.to(dev).to(tdt), v.to(dev).to(tdt), cu, cu, H, dh, max(lens), lse=lse, q_prescaled=prescaled)
+    ref = ref_attn(q_ref, k, v, lens, lens, H, dh, False)
+    assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(lse).all())
+    err = (out.cpu().double() - ref).abs().max()
+    assert err < (2e-5 if dtype == "fp32" else 1.2e-2 * max(1.0, float(ref.abs().max()))), err
 
 
 def test_patchify_and_gather(dev):
@@ -236,6 +274,34 @@ def test_gemm_nt_gelu_aux_modes(dev, dtype, shape):
         assert bool((d <= 2.0 ** -7 * ref.float().abs() + 1e-6).all()) and float((d > 0).float().mean()) < 0.01, (float(d.max()), float((d > 0).float().mean()))
     else:
         assert torch.allclose(fused, ref, rtol=1e-5, atol=1e-6)   # fp32 contraction differences between the two kernels
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("shape", [(300, 136, 64), (2048, 1536, 512), (1000, 2304, 768)])
+def test_gemm_nt_col_scale(dev, dtype, shape):
+    """acai_gemm_nt_ex scale_cols / col_scale: the first n columns of (a w^T + bias) are multiplied by s before the rounding - the
+    in-projection hands q to the attention kernels as q log2(e)/sqrt(dh); every other column is bit-identical to the plain GEMM."""
+    from acai_omr_amd import ops
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + 1)
+    dt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    a = torch.randn(M, K, generator=g).to(dev).to(dt)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev).to(dt)
+    b = torch.randn(N, generator=g).to(dev)
+    rnd = dtype == "bf16"
+    n, sc = N // 3, ops.QSCALE(64)
+    y = ops.gemm_nt(a, w, b, out_dtype=dt, round_bf16=rnd, col_scale=(n, sc))
+    plain = ops.gemm_nt(a, w, b, out_dtype=dt, round_bf16=rnd)
+    exact = ops.gemm_nt(a, w, b, out_dtype=torch.float32)   # unrounded fp32 accumulators + bias
+    assert torch.equal(y[:, n:], plain[:, n:])
+    want = (exact[:, :n] * sc).to(dt)
+    if rnd:   # same fp32 number rounded once: the two kernels may differ in the last bit of the fp32 product
+        d = (y[:, :n].float() - want.float()).abs()
+        assert bool((d <= 2.0 ** -7 * want.float().abs() + 1e-6).all()) and float((d > 0).float().mean()) < 0.01
+    else:
+        assert torch.allclose(y[:, :n], want, rtol=1e-6, atol=1e-7)
+
 
 
 @pytest.mark.gpu

@@ -51,10 +51,17 @@ def test_gemm_transposed_variants(dev, M, N, K, dtype):
     (1, 6, [5, 9, 3], None, False),
     (4, 12, [7, 12], [20, 13], False),
     (2, 64, [300], None, True),
+    (2, 32, [333, 128], None, False),      # several full tiles in front of a ragged one
+    (1, 64, [256], [400], False),
 ])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_attn_backward(dev, H, dh, lens_q, lens_k, causal, dtype):
+@pytest.mark.parametrize("prescaled", [False, True])
+def test_attn_backward(dev, H, dh, lens_q, lens_k, causal, dtype, prescaled):
+    """prescaled: the kernels get q log2(e)/sqrt(dh) (the training path's in-projection epilogue) and still return the gradient with respect
+    to the unscaled q."""
     from acai_omr_amd import engine, ops
+    if prescaled and dh % (8 if dtype == "bf16" else 4):
+        pytest.skip("the prescaled form exists for 16-byte-aligned heads only")
     lens_k = lens_k or lens_q
     g = torch.Generator().manual_seed(H * dh + sum(lens_q) + 7)
     E = H * dh
@@ -63,6 +70,9 @@ def test_attn_backward(dev, H, dh, lens_q, lens_k, causal, dtype):
     k = torch.randn(sum(lens_k), E, generator=g).to(tdt).float()
     v = torch.randn(sum(lens_k), E, generator=g).to(tdt).float()
     dout = torch.randn(sum(lens_q), E, generator=g).to(tdt).float()
+    qp = (q * ops.QSCALE(dh)).to(tdt)
+    if prescaled:
+        q = qp.float() / ops.QSCALE(dh)     # the reference differentiates with respect to the q the kernel effectively sees
     # reference: torch autograd in float64
     qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
     out = torch.zeros(sum(lens_q), E, dtype=torch.float64)
@@ -80,11 +90,13 @@ def test_attn_backward(dev, H, dh, lens_q, lens_k, causal, dtype):
     loss = sum((o * dout[a:a + l, sl].double()).sum() for a, l, sl, o in outs)
     loss.backward()
     qd, kd, vd, dd = (t.to(dev).to(tdt) for t in (q, k, v, dout))
+    if prescaled:
+        qd = qp.to(dev)
     cu_q, cu_k = engine.cu_from_lens(lens_q, dev), engine.cu_from_lens(lens_k, dev)
     lse = torch.empty(H * sum(lens_q), device=dev)
-    o = ops.attn_varlen(qd, kd, vd, cu_q, cu_k, H, dh, max(lens_q), causal=causal, lse=lse)
+    o = ops.attn_varlen(qd, kd, vd, cu_q, cu_k, H, dh, max(lens_q), causal=causal, lse=lse, q_prescaled=prescaled)
     dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
-    ops.attn_varlen_bwd(qd, kd, vd, o, dd, lse, cu_q, cu_k, H, dh, max(lens_q), max(lens_k), causal, dq, dk, dv)
+    ops.attn_varlen_bwd(qd, kd, vd, o, dd, lse, cu_q, cu_k, H, dh, max(lens_q), max(lens_k), causal, dq, dk, dv, q_prescaled=prescaled)
     tol = 3e-5 if dtype == "fp32" else 6e-2
     for name, got, ref in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
         err = (got.cpu().double() - ref).abs().max() / max(1.0, float(ref.abs().max()))
