@@ -1023,6 +1023,182 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     epi_half(std::integral_constant<int, 1>{});
 }
 
+// ---- persistent 256x256 kernel on a ring of five 32 KB half-stages (round 2) ------------------------------------------------------------
+// The short-K GEMMs of the training steps (K = 512..768: 8-12 K-tiles per output tile) are bound by what a CU takes in through the LDS-DMA
+// path - 33 GB/s from the Infinity Cache, 66-73 from its XCD's L2, and the 256x128 persistent ring sustains ~35 with ~75 % L2 hits - not by
+// the matrix cores (31 % busy).  A 256x256 tile needs 64 KB per K-tile for twice the MFMA work of the 256x128 tile's 48 KB: 1.5x the flops
+// per staged byte.  Three whole 64 KB stages do not fit the 160 KB of LDS, so the ring runs on HALF-stages: unit 2q is the A image
+// ([256 rows][128 B], the layout of the other LDS-DMA kernels) of K-step q, unit 2q+1 its W image, unit u lives in slot u % 5.  While
+// K-step q is computed (two slots), units A(q+1), W(q+1), A(q+2) are in flight in the other three: 96 KB, as much as the three-stage ring.
+// Per step: s_waitcnt vmcnt(4) (only the four DMA instructions of the youngest unit may be outstanding), ONE raw barrier, issue W(q+2) and
+// A(q+3) into the two slots step q-1 just freed, 32 MFMAs per wave.  The ring runs ACROSS output tiles (XCD-contiguous tile ranges, one
+// workgroup per CU); the epilogue stages through the two slots its last K-step read (behind one extra barrier).
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_pers256_kernel(GemmArgs g) {
+    static_assert(sizeof(T) == 2 && EPI == 0, "bf16 row-major operands, plain epilogue");
+    constexpr int BK = ROWB / sizeof(T);
+    constexpr int BT = 256, UNIT = BT * ROWB, NSLOT = 5;   // 32 KB per unit
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NSLOT * UNIT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3, lr = lane & 31, lh = lane >> 5;
+    const int nbn = (g.N + BT - 1) / BT, nbm = (g.M + BT - 1) / BT, ntiles = nbn * nbm;
+    // my tiles: XCD x = blockIdx % 8 owns a contiguous range, its workgroups interleave inside it
+    const int w = blockIdx.x, nwg = gridDim.x, xcd = w % 8, j0 = w / 8;
+    const int per_xcd = (nwg - xcd + 7) / 8;
+    const int tq = ntiles / 8, tr = ntiles % 8;
+    const int t_start = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, t_count = tq + (xcd < tr ? 1 : 0);
+    const int n_my = j0 < t_count ? (t_count - j0 + per_xcd - 1) / per_xcd : 0;
+    const int nkt = g.K / BK, total = n_my * nkt;
+    if (total == 0) return;
+    const T *A = reinterpret_cast<const T *>(g.A);
+    const T *W = reinterpret_cast<const T *>(g.W);
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr)lds;
+
+    // ---- producer: one cursor per operand (A runs one K-step ahead of W) ----
+    const int grow = lane >> 3;
+    const T *srcA[4], *srcW[4];
+    int a_tile = 0, a_kt = 0, w_tile = 0, w_kt = 0, p_slot = 0;
+    auto tile_origin = [&](int ti, int &bm0, int &bn0) {
+        const int t = t_start + j0 + ti * per_xcd;
+        bm0 = (t / nbn) * BT;
+        bn0 = (t % nbn) * BT;
+    };
+    auto set_a = [&](int ti) {
+        int bm0, bn0;
+        tile_origin(ti, bm0, bn0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave * 4 + i) * 8 + grow, gslot = (lane & 7) ^ ((row >> 1) & 7);
+            srcA[i] = A + (size_t)min(bm0 + row, g.M - 1) * g.lda + gslot * (16 / sizeof(T));
+        }
+    };
+    auto set_w = [&](int ti) {
+        int bm0, bn0;
+        tile_origin(ti, bm0, bn0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave * 4 + i) * 8 + grow, gslot = (lane & 7) ^ ((row >> 1) & 7);
+            srcW[i] = W + (size_t)min(bn0 + row, g.N - 1) * g.ldw + gslot * (16 / sizeof(T));
+        }
+    };
+    // next A / W unit -> slot p_slot; nothing once the work list is exhausted.  Two functions with a fixed call order (A W A | W A | W A ...),
+    // not one that picks the operand from the unit's parity: indexed that way the source-pointer arrays went to scratch memory, and every
+    // reload drained vmcnt to 0 in front of the next DMA
+    int a_done = 0, w_done = 0;   // K-steps issued per operand
+    auto next_slot = [&]() { p_slot = p_slot == NSLOT - 1 ? 0 : p_slot + 1; };
+    auto issue_a = [&]() {
+        if (a_done >= total) return;
+        const uint32_t lb = lds_base + p_slot * UNIT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(__builtin_amdgcn_readfirstlane(lb + (wave * 4 + i) * 1024), srcA[i] + (size_t)a_kt * BK);
+        if (++a_kt == nkt) {
+            a_kt = 0;
+            if (++a_tile < n_my) set_a(a_tile);
+        }
+        ++a_done;
+        next_slot();
+    };
+    auto issue_w = [&]() {
+        if (w_done >= total) return;
+        const uint32_t lb = lds_base + p_slot * UNIT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(__builtin_amdgcn_readfirstlane(lb + (wave * 4 + i) * 1024), srcW[i] + (size_t)w_kt * BK);
+        if (++w_kt == nkt) {
+            w_kt = 0;
+            if (++w_tile < n_my) set_w(w_tile);
+        }
+        ++w_done;
+        next_slot();
+    };
+
+    f32x16 acc[4][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    };
+    auto compute = [&](const unsigned char *sa, const unsigned char *sb) {
+        uint4 fa[2][4], fb[2][2];
+        auto frags = [&](int s4, uint4 (&xa)[4], uint4 (&xb)[2]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ra = wm * 128 + i * 32 + lr;
+                xa[i] = *reinterpret_cast<const uint4 *>(sa + ra * ROWB + (((s4 * 2 + lh) ^ ((ra >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int rb = wn * 64 + j * 32 + lr;
+                xb[j] = *reinterpret_cast<const uint4 *>(sb + rb * ROWB + (((s4 * 2 + lh) ^ ((rb >> 1) & 7)) << 4));
+            }
+        };
+        frags(0, fa[0], fb[0]);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            if (s4 + 1 < 4) frags(s4 + 1, fa[(s4 + 1) & 1], fb[(s4 + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s4 & 1][i]), __builtin_bit_cast(bf16x8, fb[s4 & 1][j]), acc[i][j], 0, 0, 0);
+        }
+    };
+
+    set_a(0);
+    set_w(0);
+    issue_a();   // A(0)
+    issue_w();   // W(0)
+    issue_a();   // A(1)
+    zero_acc();
+    int c_tile = 0, c_kt = 0, slot_a = 0;   // slot of A(q); W(q) sits in the next one
+    bool drained = false;   // the previous step ended with an epilogue: its stores are still counted in vmcnt
+    for (int q = 0; q < total; ++q) {
+        // A(q), W(q) have landed: of everything issued, only A(q+1) - the youngest unit, four instructions per wave - may be outstanding
+        if (!drained && q + 1 < total)
+            asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        drained = false;
+        issue_w();   // W(q+1) -> the slot A(q-1) left
+        issue_a();   // A(q+2) -> the slot W(q-1) left
+        const int slot_w = slot_a == NSLOT - 1 ? 0 : slot_a + 1;
+        compute(lds + slot_a * UNIT, lds + slot_w * UNIT);
+        if (++c_kt == nkt) {
+            c_kt = 0;
+            int bm0, bn0;
+            tile_origin(c_tile, bm0, bn0);
+            // the wave's 128 x 64 block as two 64 x 64 halves through the shared routines (constant indices only: a run-time index into
+            // acc would push all 128 accumulator registers to scratch)
+            const bool vec = g.vec_epi;
+            if (vec) asm volatile("s_barrier" ::: "memory");   // every wave is done reading these two slots: they become the staging space
+            auto epi_half = [&](auto ihc) {
+                constexpr int ih = decltype(ihc)::value;
+                f32x16 half[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) half[i][j] = acc[2 * ih + i][j];
+                const int bmh = bm0 + wm * 128 + ih * 64;
+                if (!vec) {
+                    gemm_epilogue<EPI, false>(g, half, bmh, bn0, 0, wn, lr, lh);
+                } else {
+                    float *stg = reinterpret_cast<float *>(lds + (wave < 4 ? slot_a : slot_w) * UNIT + (wave & 3) * (UNIT / 4));
+                    gemm_vec_epilogue<16>(g, half, stg, bmh, bn0, 0, wn, lane);
+                }
+            };
+            epi_half(std::integral_constant<int, 0>{});
+            epi_half(std::integral_constant<int, 1>{});
+            zero_acc();
+            ++c_tile;
+            drained = true;
+        }
+        slot_a = slot_a + 2 >= NSLOT ? slot_a + 2 - NSLOT : slot_a + 2;
+    }
+}
+
 // ---- dW = dY^T X on the three-stage ring (round 2) -------------------------------------------------------------------------------------
 // gemm_tn_glds_kernel keeps ONE 64-token tile in flight per workgroup (two stages, `__syncthreads()` drains the LDS-DMA): a K-step of a
 // 128x128 tile is ~0.2 us of MFMA work against >= 1 us of loaded fabric latency, and two co-resident workgroups do not cover it (0.61-0.69 PF
@@ -1205,9 +1381,23 @@ int launch(const GemmArgs &g, hipStream_t st) {
         const bool fills256 = nwg256 >= n_cu && nwg256 * 100 >= rounds256 * n_cu * 85;
         if (v == 0)
             v = nwg4 >= 512 ? (ktiles <= 24 ? 4 : (sizeof(T) == 2 && ktiles >= 64 ? (fills256 ? 5 : (nwg4 < 4 * n_cu ? 1 : 3)) : 3)) : 1;
-        if (v == 5 && nwg256 < 8) v = 1;
+        // The persistent 256x256 ring of half-stages (6) where its tiles fill whole rounds of the chip (>= 95 %): 1.5x the flops per staged byte
+        // pays on the decoder's 131072-token GEMMs and on N = 3072 (tools/bench_mae_gemms.py: lin1 + GELU 977 -> 868 us, lin2 537 -> 481,
+        // dX of the in-projection 346 -> 307); it loses where a quarter of the last round idles (N = 768: 384 tiles) and ties on K = N = 512.
+        if constexpr (sizeof(T) == 2 && EPI == 0) {
+            static const bool no_p256 = getenv("ACAI_GEMM_NO_P256") != nullptr;   // A/B aid
+            if (g_gemm_variant == 0 && !no_p256 && (v == 4 || v == 3) && ktiles < 64 && nwg256 >= n_cu && nwg256 * 100 >= rounds256 * n_cu * 95 &&
+                !(g.N <= 512 && ktiles <= 8))
+                v = 6;
+        }
+        if ((v == 5 || v == 6) && nwg256 < 8) v = 1;
         if (v == 4 && nwg4 < 8) v = 1;
         switch (v) {
+            case 6:
+                if constexpr (sizeof(T) == 2 && EPI == 0) {
+                    hipLaunchKernelGGL((gemm_nt_pers256_kernel<T, EPI>), dim3(nwg256 < n_cu ? nwg256 : n_cu), dim3(512), 0, st, h);
+                    break;
+                }
             case 5: hipLaunchKernelGGL((gemm_nt_256_kernel<T, EPI>), dim3(nwg256), dim3(512), 0, st, h); break;
             case 4: hipLaunchKernelGGL((gemm_nt_pers_kernel<T, EPI>), dim3(nwg4 < n_cu ? nwg4 : n_cu), dim3(512), 0, st, h); break;
             case 3: hipLaunchKernelGGL((gemm_nt_glds3_kernel<T, EPI>), dim3(nwg4), dim3(512), 0, st, h); break;
@@ -1226,7 +1416,7 @@ int launch(const GemmArgs &g, hipStream_t st) {
 }  // namespace
 
 extern "C" int acai_gemm_set_variant(int variant) {
-    ACAI_CHECK_ARG(variant >= 0 && variant <= 5, "acai_gemm_set_variant: 0 (auto) .. 5");
+    ACAI_CHECK_ARG(variant >= 0 && variant <= 6, "acai_gemm_set_variant: 0 (auto) .. 6");
     g_gemm_variant = variant;
     return 0;
 }

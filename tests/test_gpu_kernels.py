@@ -40,12 +40,12 @@ def test_gemm_nt(dev, M, N, K, dtype):
     _check_gemm_nt(dev, M, N, K, dtype)
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6])
 @pytest.mark.parametrize("K", [64, 128, 192, 256, 320, 704])
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
 def test_gemm_nt_three_stage_tile(dev, K, dtype, variant):
     """The large-tile LDS-DMA kernels, each pinned in turn (256x128 two-stage, three-stage with counted vmcnt waits, persistent ring across
-    tiles, 256x256): every K-tile
+    tiles, 256x256, persistent 256x256 on the ring of half-stages): every K-tile
     count modulo 3, one to many tiles, ragged M / N edges."""
     from acai_omr_amd import _lib
     if dtype == "fp32":

@@ -2,11 +2,23 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pmc_gemm
 mkdir -p $O
-i=0
-for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL" "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum"; do
-  i=$((i+1))
-  for S in "4096 4096 4096" "131072 1536 512"; do
-    timeout -k 10 120 rocprofv3 --kernel-trace --pmc $C -d $O/p${i}_$(echo $S | tr ' ' 'x') -o r --output-format csv -- python3 $R/tools/prof_gemm.py $S 3 > $O/log_${i}.txt 2>&1 || echo "pass $i $S failed"
-  done
+for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
+  T=$(echo $C | tr ' ' '_')
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $C -d $O/$T -o r --output-format csv -- python3 $R/tools/pmc_gemm.py > $O/$T.log 2>&1 || echo "$T failed"
 done
-ls $O
+python3 - $O <<'PY'
+import csv, glob, os, sys, collections
+root = sys.argv[1]
+sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"] + "/tools")
+names = ["dec qkv fwd 131072x1536x512", "dec lin1 gelu 131072x3072x512", "dec lin2 131072x512x3072", "enc qkv 32768x2304x768"]
+for d in sorted(glob.glob(root + "/*/")):
+    for f in glob.glob(d + "**/*counter_collection.csv", recursive=True):
+        rows = [r for r in csv.DictReader(open(f)) if "gemm_nt" in r["Kernel_Name"]]
+        by = collections.defaultdict(list)
+        for r in rows:
+            by[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), r["Kernel_Name"][:60]))
+        for c, v in by.items():
+            v.sort()
+            print(c, [f"{names[i // 4] if i % 4 == 0 else ''} {x[1]:.4g}" for i, x in enumerate(v)])
+PY
+rm -f $(find $O -name "*kernel_trace.csv")
