@@ -91,11 +91,13 @@ class LinearFn(Function):
     """y = x @ W^T + b (+ residual).  x in the compute dtype; y fp32 when a residual is added, else compute dtype (or fp32 on request)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, residual, prec, wc, out_fp32):
+    def forward(ctx, x, W, b, residual, prec, wc, out_fp32, col_scale=None):
+        """col_scale = (n, s): the first n output columns leave the epilogue multiplied by s (a q projection for attention kernels that take a
+        prescaled q; the attention backward returns the gradient w.r.t. the UNSCALED output, so nothing changes below)."""
         bf = prec == "bf16"
         Wc, bc = wc.w(W, prec), wc.b(b, prec)
         out_dtype = torch.float32 if (residual is not None or out_fp32 or not bf) else torch.bfloat16
-        y = ops.gemm_nt(x, Wc, bc, residual=residual, out_dtype=out_dtype, round_bf16=bf)
+        y = ops.gemm_nt(x, Wc, bc, residual=residual, out_dtype=out_dtype, round_bf16=bf, col_scale=col_scale)
         ctx.save_for_backward(x, W)
         ctx.prec, ctx.wc, ctx.has_res, ctx.has_bias = prec, wc, residual is not None, b is not None
         return y
@@ -110,7 +112,7 @@ class LinearFn(Function):
         dx = ops.gemm_nt(dyc, ctx.wc.wt(W, prec), out_dtype=x.dtype) if ctx.needs_input_grad[0] else None
         dW = ops.gemm(dyc, x, trans_a=True, trans_w=True, out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
         db = (cs if cs is not None else ops.colsum(dyc)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return dx, dW, db, dres, None, None, None
+        return dx, dW, db, dres, None, None, None, None
 
 
 def _compute_copy(x32, prec):
@@ -188,7 +190,7 @@ class SelfAttnBlockFn(Function):
         x = _compute_copy(x32, prec)
         # the in-projection's epilogue hands q over as q * log2(e) / sqrt(dh) (one rounding, after the scale - torch's math SDPA scales q
         # before the product too): the attention kernels then spend no multiply per score.  The saved qkv holds that q'.
-        pre = _QPRESCALE and bf and E % 8 == 0 and dh % 8 == 0
+        pre = _q_prescale(prec, E, dh)
         qkv = ops.gemm_nt(x, wc.w(Wi, prec), wc.b(bi, prec), out_dtype=cdt, round_bf16=bf, col_scale=(E, ops.QSCALE(dh)) if pre else None)
         lse = torch.empty(H * x.shape[0], dtype=torch.float32, device=x.device)
         attn = ops.attn_varlen(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], cu, cu, H, dh, max_len, causal=causal, lse=lse, q_prescaled=pre)
@@ -240,50 +242,52 @@ class SelfAttnFn(Function):
     """Packed self attention on a fused qkv tensor [M, 3E] -> [M, E]."""
 
     @staticmethod
-    def forward(ctx, qkv, cu, H, dh, max_len, causal, dropout_p=0.0):
+    def forward(ctx, qkv, cu, H, dh, max_len, causal, dropout_p=0.0, pre=False):
+        """pre: the q columns of qkv are prescaled (LinearFn col_scale); dqkv is w.r.t. the unscaled projection either way."""
         E = H * dh
         M = qkv.shape[0]
         lse = torch.empty(H * M, dtype=torch.float32, device=qkv.device)
         seed = _next_seed() if dropout_p > 0 else 0
-        out = ops.attn_varlen(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], cu, cu, H, dh, max_len, causal=causal, lse=lse, dropout_p=dropout_p, seed=seed)
+        out = ops.attn_varlen(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], cu, cu, H, dh, max_len, causal=causal, lse=lse, dropout_p=dropout_p, seed=seed,
+                              q_prescaled=pre)
         ctx.save_for_backward(qkv, out, lse, cu)
-        ctx.cfg = (H, dh, max_len, causal, dropout_p, seed)
+        ctx.cfg = (H, dh, max_len, causal, dropout_p, seed, pre)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, out, lse, cu = ctx.saved_tensors
-        H, dh, max_len, causal, dropout_p, seed = ctx.cfg
+        H, dh, max_len, causal, dropout_p, seed, pre = ctx.cfg
         E = H * dh
         dqkv = torch.empty_like(qkv)
         dout = dout.contiguous().to(qkv.dtype)
         ops.attn_varlen_bwd(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], out, dout, lse, cu, cu, H, dh, max_len, max_len, causal,
-                            dqkv[:, :E], dqkv[:, E:2 * E], dqkv[:, 2 * E:], dropout_p=dropout_p, seed=seed)
-        return dqkv, None, None, None, None, None, None
+                            dqkv[:, :E], dqkv[:, E:2 * E], dqkv[:, 2 * E:], dropout_p=dropout_p, seed=seed, q_prescaled=pre)
+        return dqkv, None, None, None, None, None, None, None
 
 
 class CrossAttnFn(Function):
     """Packed cross attention: q [Mq, E], kv [Mk, 2E] -> [Mq, E]."""
 
     @staticmethod
-    def forward(ctx, q, kv, cu_q, cu_k, H, dh, max_q, max_k, dropout_p=0.0):
+    def forward(ctx, q, kv, cu_q, cu_k, H, dh, max_q, max_k, dropout_p=0.0, pre=False):
         E = H * dh
         lse = torch.empty(H * q.shape[0], dtype=torch.float32, device=q.device)
         seed = _next_seed() if dropout_p > 0 else 0
-        out = ops.attn_varlen(q, kv[:, :E], kv[:, E:], cu_q, cu_k, H, dh, max_q, lse=lse, dropout_p=dropout_p, seed=seed)
+        out = ops.attn_varlen(q, kv[:, :E], kv[:, E:], cu_q, cu_k, H, dh, max_q, lse=lse, dropout_p=dropout_p, seed=seed, q_prescaled=pre)
         ctx.save_for_backward(q, kv, out, lse, cu_q, cu_k)
-        ctx.cfg = (H, dh, max_q, max_k, dropout_p, seed)
+        ctx.cfg = (H, dh, max_q, max_k, dropout_p, seed, pre)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, kv, out, lse, cu_q, cu_k = ctx.saved_tensors
-        H, dh, max_q, max_k, dropout_p, seed = ctx.cfg
+        H, dh, max_q, max_k, dropout_p, seed, pre = ctx.cfg
         E = H * dh
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
         ops.attn_varlen_bwd(q, kv[:, :E], kv[:, E:], out, dout.contiguous().to(q.dtype), lse, cu_q, cu_k, H, dh, max_q, max_k, False,
-                            dq, dkv[:, :E], dkv[:, E:], dropout_p=dropout_p, seed=seed)
-        return dq, dkv, None, None, None, None, None, None, None
+                            dq, dkv[:, :E], dkv[:, E:], dropout_p=dropout_p, seed=seed, q_prescaled=pre)
+        return dq, dkv, None, None, None, None, None, None, None, None
 
 
 class DropoutAddFn(Function):
@@ -430,15 +434,21 @@ def _self_attn_block(x32, sa, cu, H, max_len, causal, p_attn, p_out, prec, wc):
     if _FUSED_MLP and p_attn <= 0.0 and p_out <= 0.0 and sa.in_proj_bias is not None and sa.out_proj.bias is not None:
         return SelfAttnBlockFn.apply(x32, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, cu, H, max_len, causal, prec, wc)
     E = x32.shape[1]
-    qkv = _lin(x32, sa.in_proj_weight, sa.in_proj_bias, prec, wc)
-    attn = SelfAttnFn.apply(qkv, cu, H, E // H, max_len, causal, p_attn)
+    pre = _q_prescale(prec, E, E // H)
+    qkv = _lin(x32, sa.in_proj_weight, sa.in_proj_bias, prec, wc, col_scale=(E, ops.QSCALE(E // H)) if pre else None)
+    attn = SelfAttnFn.apply(qkv, cu, H, E // H, max_len, causal, p_attn, pre)
     return _proj_residual(attn, sa.out_proj.weight, sa.out_proj.bias, x32, p_out, prec, wc)
 
 
-def _lin(x32, lin_w, lin_b, prec, wc, residual=None, out_fp32=False):
+def _q_prescale(prec, E, dh):
+    """Whether q leaves its projection already scaled for the attention kernels (bf16 path, 16-byte-aligned heads)."""
+    return _QPRESCALE and prec == "bf16" and E % 8 == 0 and dh % 8 == 0
+
+
+def _lin(x32, lin_w, lin_b, prec, wc, residual=None, out_fp32=False, col_scale=None):
     """nn.Linear on an fp32 activation: casts to the compute dtype (autocast's input cast) and applies LinearFn."""
     x = CastBf16Fn.apply(x32) if (prec == "bf16" and x32.dtype != torch.bfloat16) else x32
-    return LinearFn.apply(x, lin_w, lin_b, residual, prec, wc, out_fp32)
+    return LinearFn.apply(x, lin_w, lin_b, residual, prec, wc, out_fp32, col_scale)
 
 
 def encoder_stack(stack, x32, cu, max_len, H, prec, wc, training=False):
@@ -753,13 +763,14 @@ def decoder_forward(dec, input_seqs, img_latent, lmx_attention_mask, latent_atte
         y = _self_attn_block(x32, sa, cu_t, H, mt, True, _p_of(sa, tr), _p_of(ly.dropout1, tr), prec, wc)
         x32 = LayerNormFn.apply(y, ly.norm1.weight, ly.norm1.bias, ly.norm1.eps)
         xc = CastBf16Fn.apply(x32) if bf else x32
-        q = LinearFn.apply(xc, ca.in_proj_weight[:E], ca.in_proj_bias[:E], None, prec, _SliceCache(wc, ca, 0, E), False)
+        pre = _q_prescale(prec, E, dh)
+        q = LinearFn.apply(xc, ca.in_proj_weight[:E], ca.in_proj_bias[:E], None, prec, _SliceCache(wc, ca, 0, E), False, (E, ops.QSCALE(dh)) if pre else None)
         kv = None if share is None else share["kv"].get(li)
         if kv is None:
             kv = LinearFn.apply(memc, ca.in_proj_weight[E:], ca.in_proj_bias[E:], None, prec, _SliceCache(wc, ca, E, 3 * E), False)
             if share is not None:
                 share["kv"][li] = kv
-        a = CrossAttnFn.apply(q, kv, cu_t, cu_s, H, dh, mt, ms, _p_of(ca, tr))
+        a = CrossAttnFn.apply(q, kv, cu_t, cu_s, H, dh, mt, ms, _p_of(ca, tr), pre)
         y = _proj_residual(a, ca.out_proj.weight, ca.out_proj.bias, x32, _p_of(ly.dropout2, tr), prec, wc)
         x32 = LayerNormFn.apply(y, ly.norm2.weight, ly.norm2.bias, ly.norm2.eps)
         y = _mlp(x32, ly.linear1, ly.linear2, _p_of(ly.dropout, tr), _p_of(ly.dropout3, tr), prec, wc)

@@ -232,17 +232,31 @@ def bench_mae(dev, rank, world, dist, batch, height, width, steps, dtype, want_c
                includes="forward + MAELoss + backward" + (" + RCCL gradient all-reduce" if world > 1 else "") + " + fused AdamW step",
                loss=float(loss.detach()), tflops_algorithmic=step_flops / (ms * 1e-3) / 1e12)
     del opt, ddp
-    # dominant kernel by time: the d_h = 32 self-attention of the 8-layer MAE decoder over all n patches (forward form), timed live
+    # dominant kernels by time: the d_h = 32 self-attention of the 8-layer MAE decoder over all n patches, timed live exactly as the step issues
+    # them (q prescaled by the in-projection's epilogue).  `roofline` is the forward kernel; the backward pair (dQ kernel + dK/dV kernel, the
+    # largest single item of the step) is reported beside it against its algorithmic 5 products.
     H, dh = 16, 32
+    pre = dtype == "bf16"
     qkv = torch.randn(batch * n, 3 * H * dh, device=dev).to(torch.bfloat16 if dtype == "bf16" else torch.float32)
     cu = EG.cu_from_lens([n] * batch, dev)
     E = H * dh
-    k_s = time_launches(lambda i: ops.attn_varlen(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], cu, cu, H, dh, n), 2, 8)
+    q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
+    lse = torch.empty(H * batch * n, dtype=torch.float32, device=dev)
+    o = ops.attn_varlen(q, k, v, cu, cu, H, dh, n, lse=lse, q_prescaled=pre)
+    k_s = time_launches(lambda i: ops.attn_varlen(q, k, v, cu, cu, H, dh, n, lse=lse, q_prescaled=pre), 2, 8)
+    dout, dqkv = torch.randn_like(o), torch.empty_like(qkv)
+    b_s = time_launches(lambda i: ops.attn_varlen_bwd(q, k, v, o, dout, lse, cu, cu, H, dh, n, n, False, dqkv[:, :E], dqkv[:, E:2 * E], dqkv[:, 2 * E:],
+                                                      q_prescaled=pre), 2, 6)
     k_flops = 4.0 * batch * H * n * n * dh
-    out["roofline"] = dict(bound="mfma", kernel=f"attn_fwd_kernel<{dtype}, d_h=32> (MAE decoder self-attention, one layer, {batch} x {n} tokens)",
+    out["roofline"] = dict(bound="mfma", kernel=f"attn_fwd_kernel<{dtype}, d_h=32, q prescaled> (MAE decoder self-attention, one layer, {batch} x {n} tokens)",
                            achieved=k_flops / k_s / 1e12, peak=MFMA_PEAK_TFS, unit="TFLOP/s", frac=k_flops / k_s / 1e12 / MFMA_PEAK_TFS,
                            traffic=None, kernel_us=k_s * 1e6, flops_per_launch=k_flops, step_flops=step_flops,
-                           step_achieved_TFs=step_flops / (ms * 1e-3) / 1e12, step_frac=step_flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFS)
+                           step_achieved_TFs=step_flops / (ms * 1e-3) / 1e12, step_frac=step_flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFS,
+                           backward_pair=dict(kernels="attn_bwd_dq_kernel + attn_bwd_dkv_kernel (same layer)", us=b_s * 1e6,
+                                              flops_algorithmic=2.5 * k_flops, achieved=2.5 * k_flops / b_s / 1e12,
+                                              frac=2.5 * k_flops / b_s / 1e12 / MFMA_PEAK_TFS),
+                           note="VALU-issue bound, not MFMA bound: per score the forward issues one exp2, one add and half a pack (PMC in DESIGN.md section 6)")
+    del o, dout, dqkv, lse
     del mae, qkv
     torch.cuda.empty_cache()
     if want_cpu:
