@@ -1381,6 +1381,10 @@ int launch(const GemmArgs &g, hipStream_t st) {
         const bool fills256 = nwg256 >= n_cu && nwg256 * 100 >= rounds256 * n_cu * 85;
         if (v == 0)
             v = nwg4 >= 512 ? (ktiles <= 24 ? 4 : (sizeof(T) == 2 && ktiles >= 64 ? (fills256 ? 5 : (nwg4 < 4 * n_cu ? 1 : 3)) : 3)) : 1;
+        // Mid-size problems at 16-24 K-tiles (the teacher-forced decoder stream: 8208 rows, K = 1024): two co-resident 128x128 workgroups beat the
+        // persistent ring until it has ~8 rounds of tiles to run across (tools/bench_gemm_tf.py: N = 3072 89 -> 80 us, N = 4096 116 -> 100 us at
+        // M = 8208; still ahead at M = 20000)
+        if (g_gemm_variant == 0 && v == 4 && ktiles >= 16 && nwg4 < 2048) v = 1;
         // The persistent 256x256 ring of half-stages (6) where its tiles fill whole rounds of the chip (>= 95 %): 1.5x the flops per staged byte
         // pays on the decoder's 131072-token GEMMs and on N = 3072 (tools/bench_mae_gemms.py: lin1 + GELU 977 -> 868 us, lin2 537 -> 481,
         // dX of the in-projection 346 -> 307); it loses where a quarter of the last round idles (N = 768: 384 tiles) and ties on K = N = 512.
