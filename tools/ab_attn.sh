@@ -15,7 +15,7 @@ for v in ${ACAI_AB_VARIANTS:-main s3 s2}; do
   ACAI_OMR_LIB=$(libof $v) timeout -k 10 200 python3 tools/bench_attn.py 10 2>&1 | tee $O/bench_$v.log | grep -v Warn
 done
 cd /tmp
-export ACAI_BENCH_ATTN_ONLY=mae-decoder
+export ACAI_BENCH_ATTN_ONLY=${ACAI_BENCH_ATTN_ONLY:-mae-decoder}
 for v in ${ACAI_AB_PMC_VARIANTS:-main}; do
   export ACAI_OMR_LIB=$(libof $v)
   timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS -d $O/pmcA_$v -o r --output-format csv -- python3 $R/tools/bench_attn.py 2 > $O/pmcA_$v.log 2>&1 || echo "pmcA $v failed"
