@@ -144,6 +144,17 @@ def test_attn_varlen(dev, H, dh, lens_q, lens_k, causal, dtype, prescaled):
     assert err < (2e-5 if dtype == "fp32" else 1.2e-2 * max(1.0, float(ref.abs().max()))), err
 
 
+def test_attn_varlen_prescaled_needs_aligned_heads(dev):
+    """The prescaled-q form exists for 16-byte-aligned head rows only: anything else fails loudly instead of silently taking another path."""
+    from acai_omr_amd import engine, ops
+    H, dh, lens = 2, 12, [9, 5]
+    qkv = torch.randn(sum(lens), 3 * H * dh).to(dev).to(torch.bfloat16)
+    cu = engine.cu_from_lens(lens, dev)
+    E = H * dh
+    with pytest.raises(RuntimeError, match="q_prescaled"):
+        ops.attn_varlen(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], cu, cu, H, dh, max(lens), q_prescaled=True)
+
+
 @pytest.mark.parametrize("prescaled", [False, True])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_attn_varlen_reference_maximum_restart(dev, dtype, prescaled):
