@@ -149,6 +149,23 @@ class DecodeEngine:
     # keys per cross-attention workgroup (split over the memory, merged in the launch).  1024 (4 splits of S = 4096, 512 workgroups) measured
     # +2.8 % tokens/s over 512 on the same box; 256 and 2048 are slower.  ACAI_CROSS_CHUNK overrides (A/B aid).
     CROSS_CHUNK = int(os.environ.get("ACAI_CROSS_CHUNK", "1024"))
+    CROSS_SLOTS = 512   # cross-attention workgroups resident at once (two per CU on 256 CUs)
+
+    @classmethod
+    def pick_cross_chunk(cls, lens, H):
+        """Keys per cross-attention workgroup for this batch.  A uniform batch of 8 x 4096 gives 4 x 8 x 16 = 512 workgroups of 1024 keys: one
+        full round of the chip.  A RAGGED batch does not: config 4 (1024 ... 9216 patches) makes 624 workgroups of 1024 keys - a second, mostly
+        empty round.  The chunk is therefore the multiple of 64 that minimises rounds x keys per workgroup (ties go to CROSS_CHUNK): 1344 keys
+        = 512 workgroups for config 4.  ACAI_CROSS_CHUNK pins it (A/B aid)."""
+        if "ACAI_CROSS_CHUNK" in os.environ or not lens:
+            return cls.CROSS_CHUNK
+        best, best_cost = cls.CROSS_CHUNK, None
+        for c in [cls.CROSS_CHUNK] + list(range(512, 4096 + 1, 64)):
+            n = sum(-(-l // c) for l in lens) * H
+            cost = -(-n // cls.CROSS_SLOTS) * (min(c, max(lens)) + 72)   # + ~72 keys' worth of per-workgroup cost (512- against 1024-key chunks on 8 x 4096: -2.8 % tokens/s)
+            if best_cost is None or cost < best_cost:
+                best, best_cost = c, cost
+        return best
 
     def __init__(self, blocks, omr, max_batch_size, max_len, prec, device):
         self.blocks = blocks        # CachedTransformerDecoder mirror (layers, norm): parameters are read from it
@@ -237,7 +254,8 @@ class DecodeEngine:
             ops.cross_kv_prefill(mem, w, b, row_seq, row_pos, pre_off, pre_len, self.k_cross[i], self.v_cross[i],
                                  H, self.dh, dhp, round_bf16=self.bf)
         self.B, self.lens, self.group = B, [l for l in lens for _ in range(G)], G
-        self.cross_nsplit = max(1, -(-max(lens) // self.CROSS_CHUNK))
+        self.cross_chunk = self.pick_cross_chunk(lens, H) if G == 1 else self.CROSS_CHUNK
+        self.cross_nsplit = max(1, -(-max(lens) // self.cross_chunk))
         need = B * H * max(self.cross_nsplit, self.self_nsplit) * (dhp + 2)
         if self.partial is None or self.partial.numel() < need:
             self.partial = torch.empty(self.Bmax * H * max(self.cross_nsplit, self.self_nsplit) * (dhp + 2), dtype=torch.float32, device=dev)
@@ -277,7 +295,7 @@ class DecodeEngine:
         d.flags = _lib.GEMM_ROUND_BF16 if self.bf else 0
         d.max_len = self.Tmax
         d.cross_group = self.group
-        d.self_chunk, d.cross_chunk, d.self_nsplit, d.cross_nsplit = self.SELF_CHUNK, self.CROSS_CHUNK, self.self_nsplit, self.cross_nsplit
+        d.self_chunk, d.cross_chunk, d.self_nsplit, d.cross_nsplit = self.SELF_CHUNK, getattr(self, "cross_chunk", self.CROSS_CHUNK), self.self_nsplit, self.cross_nsplit
         d.layers = ctypes.cast(layers, ctypes.POINTER(_lib.AcaiDecLayer))
         top = {}
         if nrm is not None:
@@ -410,7 +428,7 @@ class DecodeEngine:
     def ensure_graph(self, nsteps=1):
         """hipGraph of `nsteps` consecutive decode steps for the current (B, cross split) configuration.  Must run on self.stream."""
         B = self.B
-        key = (B, self.cross_nsplit, nsteps, self._sampler, self.group)
+        key = (B, self.cross_nsplit, getattr(self, "cross_chunk", self.CROSS_CHUNK), nsteps, self._sampler, self.group)
         g = self.graphs.get(key)
         if g is None:
             st = ops._st()

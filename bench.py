@@ -107,7 +107,7 @@ def time_decode_attn_kernels(eng, iters=48):
     q = torch.randn(eng.B, 3 * eng.E, device=eng.device)
     out = eng.ws["attn"]
     args = lambda l: (q.data_ptr(), q.stride(0), eng.k_cross[l].data_ptr(), eng.v_cross[l].data_ptr(), eng.cross_off.data_ptr(),  # noqa: E731
-                      eng.cross_len.data_ptr(), eng.partial.data_ptr(), out.data_ptr(), out.stride(0), eng.B, eng.H, eng.dh, eng.dhp, eng.CROSS_CHUNK,
+                      eng.cross_len.data_ptr(), eng.partial.data_ptr(), out.data_ptr(), out.stride(0), eng.B, eng.H, eng.dh, eng.dhp, getattr(eng, "cross_chunk", eng.CROSS_CHUNK),
                       eng.cross_nsplit, _lib.ACAI_BF16 if eng.bf else _lib.ACAI_F32, 1 if eng.bf else 0, eng.tickets.data_ptr(), ops._st())
     return time_launches(lambda i: _lib.check(L.acai_decode_attn(*args(i % eng.L)), "acai_decode_attn"), eng.L, iters)
 
