@@ -103,6 +103,37 @@ def test_attn_backward(dev, H, dh, lens_q, lens_k, causal, dtype, prescaled):
         assert err < tol, (name, float(err))
 
 
+@pytest.mark.parametrize("H,dh,S,B", [(16, 32, 4096, 2), (12, 64, 4096, 1)])
+def test_attn_prescaled_at_benchmark_size(dev, H, dh, S, B):
+    """The attention kernels at the benchmarked sequence length (MAE decoder: 4096 tokens, 16 heads of 32; encoder: 12 heads of 64), bf16,
+    through size-independent properties: rows of P sum to one (V = 1 gives 1), and the prescaled-q form (fast loops, accumulators started at
+    -m / -lse) agrees with the plain form on the output, the log-sum-exp and all three gradients."""
+    from acai_omr_amd import engine, ops
+    g = torch.Generator().manual_seed(S + dh)
+    E = H * dh
+    qkv = (torch.randn(B * S, 3 * E, generator=g) * 0.7).to(dev).to(torch.bfloat16)
+    q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
+    qp = (q.float() * ops.QSCALE(dh)).to(torch.bfloat16)
+    q_eff = (qp.float() / ops.QSCALE(dh)).to(torch.bfloat16)   # what the prescaled kernels effectively see, for the plain kernels
+    cu = engine.cu_from_lens([S] * B, dev)
+    ones = torch.ones_like(v)
+    for pre, qq in ((False, q_eff), (True, qp)):
+        o1 = ops.attn_varlen(qq, k, ones, cu, cu, H, dh, S, q_prescaled=pre)
+        assert float((o1.float() - 1.0).abs().max()) < 2e-2
+    lse0, lse1 = torch.empty(H * B * S, device=dev), torch.empty(H * B * S, device=dev)
+    o0 = ops.attn_varlen(q_eff, k, v, cu, cu, H, dh, S, lse=lse0)
+    o1 = ops.attn_varlen(qp, k, v, cu, cu, H, dh, S, lse=lse1, q_prescaled=True)
+    assert float((o0.float() - o1.float()).abs().max()) < 3e-2 and float((lse0 - lse1).abs().max()) < 2e-2
+    dout = torch.randn(B * S, E, generator=g).to(dev).to(torch.bfloat16)
+    d0, d1 = torch.empty_like(qkv), torch.empty_like(qkv)
+    ops.attn_varlen_bwd(q_eff, k, v, o0, dout, lse0, cu, cu, H, dh, S, S, False, d0[:, :E], d0[:, E:2 * E], d0[:, 2 * E:])
+    ops.attn_varlen_bwd(qp, k, v, o1, dout, lse1, cu, cu, H, dh, S, S, False, d1[:, :E], d1[:, E:2 * E], d1[:, 2 * E:], q_prescaled=True)
+    for sl in (slice(0, E), slice(E, 2 * E), slice(2 * E, 3 * E)):
+        a, b = d0[:, sl].float(), d1[:, sl].float()
+        assert float((a - b).abs().max()) < 3e-2 * max(1.0, float(a.abs().max())), sl
+        assert float(torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0)) > 0.9995
+
+
 def test_row_kernels_backward(dev):
     from acai_omr_amd import ops
     g = torch.Generator().manual_seed(5)
