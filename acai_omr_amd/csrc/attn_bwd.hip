@@ -282,6 +282,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     // (16 v_mov per tile) and split the tile into blocks the scheduler could not cross.
     constexpr bool STRAIGHT = !(ES == 4 && DHP == 64);   // fp32 d_h = 64 would spill with both blocks live: it stays in the general loop
     const int n_fast = (STRAIGHT && !a.causal) ? min(nkt, lk / TT) : 0;
+    // a wave whose 32 queries all lie past the sequence end (513 decoder tokens: the fifth 128-query block holds ONE row) only helps with the
+    // staging, in a loop of its own (see attn_fwd_kernel)
+    const bool wave_active = q0 + wave * 32 < lq;
+    if (!wave_active) {
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (kt + 1 < nkt) {
+                stg.load(kt + 1, lk);
+                stg.store(smem + ((kt + 1) & 1) * STAGE);
+            }
+            __syncthreads();
+        }
+    } else {
     for (int kt = 0; kt < n_fast; ++kt) {
         const unsigned char *ldsK = smem + (kt & 1) * STAGE, *ldsV = ldsK + TT * RP;
         if (kt + 1 < nkt) stg.load(kt + 1, lk);
@@ -333,6 +345,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         if (kt + 1 < nkt) stg.store(smem + ((kt + 1) & 1) * STAGE);
         __syncthreads();
     }
+    }   // wave_active
     if (my_q < lq) {
         T *row = DQ + (size_t)my_q * a.lddq;
 #pragma unroll

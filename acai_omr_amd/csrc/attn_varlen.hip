@@ -256,6 +256,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     f32x16 minit;   // PRE: start value of the score accumulators
 #pragma unroll
     for (int e = 0; e < 16; ++e) minit[e] = PRE ? -m_run : 0.f;
+    // A wave whose 32 queries all lie past the end of the sequence (513 decoder tokens: the fifth 128-query block holds ONE row) only helps
+    // with the staging: it skips the products and the softmax, which leaves the CU's issue slots to the co-resident workgroups.  Its own loop,
+    // so that the working waves' loop stays one basic block.
+    const bool wave_active = q0 + wave * 32 < lq;
+    if (!wave_active) {
+        for (int kt = 0; kt < n_fast; ++kt) {
+            if (kt + 1 < nkt) {
+                load_tile(kt + 1);
+                store_tile(lds + ((kt + 1) & 1) * STAGE);
+            }
+            __syncthreads();
+        }
+    } else
     for (int kt = 0; kt < n_fast; ++kt) {
         const unsigned char *ldsK = lds + (kt & 1) * STAGE, *ldsV = ldsK + KT * KPITCH;
         if (kt + 1 < nkt) load_tile(kt + 1);
@@ -292,6 +305,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     }
 
     // ---- general loop: masked tiles (ragged end, causal diagonal) and restarted workgroups: online softmax with a running maximum ------
+    if (!wave_active) {
+        for (int kt = kt0; kt < nkt; ++kt) {
+            if (kt + 1 < nkt) {
+                load_tile(kt + 1);
+                store_tile(lds + ((kt + 1) & 1) * STAGE);
+            }
+            __syncthreads();
+        }
+    } else
     for (int kt = kt0; kt < nkt; ++kt) {
         const unsigned char *ldsK = lds + (kt & 1) * STAGE, *ldsV = ldsK + KT * KPITCH;
         if (kt + 1 < nkt) load_tile(kt + 1);
