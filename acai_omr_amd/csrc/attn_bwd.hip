@@ -323,6 +323,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         const bool interior = (kt + 1) * TT <= (a.causal ? min(lk, q0 + wave * 32 + 1) : lk);  // every key valid for the whole wave
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            if (kt * TT + kb * 32 >= lk) continue;   // a 32-key block entirely past the sequence end
             f32x16 sacc, dpacc = pinit;
 #pragma unroll
             for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
@@ -542,6 +543,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) 
         }
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
+            if (qt * TT + qb * 32 >= lq) continue;   // a 32-query block entirely past the sequence end (513 tokens: the last tile holds one row)
             f32x16 sacc, dpacc;
             f32x4 nlse4[4], ndl4[4];
             s_dp(cur, qb, sacc, dpacc, nlse4, ndl4);
