@@ -95,7 +95,7 @@ class Encoder(nn.Module):
                 base += h_p * w_p
                 extra.append(grid)
             else:
-                rows = (torch.arange(h_p, dtype=torch.int32).unsqueeze(1) * self.pe_max_width + torch.arange(w_p, dtype=torch.int32).unsqueeze(0)).reshape(-1)
+                rows = (torch.arange(h_p, dtype=torch.int32).unsqueeze(1) * self.pos_embedding.shape[1] + torch.arange(w_p, dtype=torch.int32).unsqueeze(0)).reshape(-1)
             if select is not None:
                 rows = rows[select[i]]
             idx.append(rows)
@@ -125,6 +125,9 @@ class Encoder(nn.Module):
             r0 += ops.patchify(t, P, patches, r0)
         pe = self._pe_packed(dims)
         wc = _wc(self)
+        if not isinstance(self.projection, nn.Linear):     # a swapped-in module (the reference's tests use nn.Identity, tests/test_mae.py:12)
+            x32 = (self.projection(patches.float()) + pe).contiguous()
+            return x32, (ops.cast_bf16(x32) if bf else None), lens, dims
         x32 = ops.gemm_nt(patches, wc.w(self.projection.weight, prec), wc.b(self.projection.bias, prec), residual=pe,
                           out_dtype=torch.float32, round_bf16=bf)
         return x32, (ops.cast_bf16(x32) if bf else None), lens, dims
@@ -151,7 +154,9 @@ class Encoder(nn.Module):
     # ---- reference API ----------------------------------------------------------------------------------------------
     def batchify(self, x):
         x32, _, lens, _ = self.embed_packed(x)
-        return EG.pad_rows(x32, lens)
+        # the reference pads the patch rows with zeros and THEN projects (M:55-62): a padded row holds projection(0) = the bias
+        bias = getattr(self.projection, "bias", None)
+        return EG.pad_rows(x32, lens, None if bias is None else bias.detach())
 
     def forward(self, x):
         x32, _, lens = self.forward_packed(x)
@@ -184,6 +189,18 @@ class MAEEncoder(Encoder):
         seq_mask = torch.ones(n, device=noise.device, dtype=torch.int)
         seq_mask[:len_keep] = 0
         return ids_shuffle[:len_keep], ids_restore, seq_mask.index_select(0, ids_restore), len_keep
+
+    def mask_sequence(self, t: torch.Tensor, h_p: int, w_p: int, noise=None):
+        """M:106-125 -> (t_masked, pos_embed_slice, unmasked_seq_len, len_keep, seq_mask, ids_restore) for ONE unfolded image
+        t (1, C P^2, L).  `noise` (optional, (L,)) injects the masking noise the reference draws with torch.rand (M:110)."""
+        from ..train import autograd_path
+        return autograd_path.mae_mask_sequence(self, t, h_p, w_p, noise)
+
+    def batchify(self, x, noises=None):
+        """M:128-173 -> (embeddings (B, L_keep_max, E), encoder_attention_mask, decoder_attention_mask, kept_seq_lens, unmasked_seq_lens,
+        batch_seq_masks (jagged int32), batch_ids_restore (jagged), patchified_dims)."""
+        from ..train import autograd_path
+        return autograd_path.mae_encoder_batchify(self, x, noises)
 
     def forward(self, x, noises=None):
         from ..train import autograd_path
@@ -220,6 +237,12 @@ class MAE(nn.Module):
         nn.init.trunc_normal_(self.mask_token, std=0.1)
         nn.init.trunc_normal_(self.decoder_pos_embedding, std=0.1)
         self.unfold = nn.Unfold(kernel_size=self.patch_size, stride=self.patch_size)
+
+    def prepare_for_decoder(self, latent: torch.Tensor, kept_seq_lens, unmasked_seq_lens, batch_ids_restore: torch.Tensor, patchified_dims):
+        """M:219-241: per sequence drop the padding, append mask tokens, unshuffle by ids_restore, add the decoder PE slice; returns the
+        zero-padded (B, L_max, D) decoder input."""
+        from ..train import autograd_path
+        return autograd_path.mae_prepare_for_decoder(self, latent, kept_seq_lens, unmasked_seq_lens, batch_ids_restore, patchified_dims)
 
     def forward(self, batch, noises=None):
         """`noises`: optional list of per-image noise vectors (injected masking noise for parity runs; the reference draws
@@ -557,6 +580,28 @@ class GRPOViTOMR(ViTOMR):
         img_latent = img_latent.unsqueeze(1).expand(-1, group_size, -1, -1).flatten(start_dim=0, end_dim=1)
         latent_attention_mask = latent_attention_mask.unsqueeze(1).expand(-1, group_size, -1).flatten(start_dim=0, end_dim=1)
         return img_latent, latent_attention_mask
+
+    def uncached_forward_rollout_policy(self, img_latent, latent_attention_mask, max_actions=768, top_k=50, temperature=1.2):
+        """The reference's deprecated rollout policy without KV caching (M:897-945; "absurdly slow ... treated as deprecated"): every step
+        re-runs `decoder.generate` (the uncached HIP forward) on the whole prefix.  Its arithmetic differs from the cached policy's and is kept:
+        log-probs are log_softmax over the FULL vocabulary of the top-k-masked logits divided by the temperature, the outputs are not clipped
+        to the longest rollout.  Only the small per-step glue (top-k of 227 logits, the multinomial draw) runs as torch ops."""
+        device = img_latent.device
+        R = img_latent.shape[0]
+        rollouts = torch.full([R, max_actions], fill_value=self.decoder.pad_idx, dtype=torch.long, device=device)
+        rollouts[:, 0] = self.decoder.bos_idx
+        rollout_log_probs = torch.zeros_like(rollouts, dtype=torch.float, device=device)
+        for t in range(1, max_actions):
+            logits = self.decoder.generate(rollouts[:, :t], img_latent, latent_attention_mask=latent_attention_mask)[:, -1, :].float()
+            top_k_logits, top_k_indices = torch.topk(logits, top_k, dim=-1)
+            softmax_logits = torch.full_like(logits, float("-inf")).scatter(-1, top_k_indices, top_k_logits) / temperature
+            next_token_idxs = torch.multinomial(F.softmax(softmax_logits, dim=-1), num_samples=1)
+            rollouts[:, t] = next_token_idxs.squeeze(1)
+            rollout_log_probs[:, t] = F.log_softmax(softmax_logits, dim=-1).gather(-1, index=next_token_idxs).squeeze(1)
+            if torch.all(torch.any(rollouts == self.decoder.eos_idx, dim=-1)):
+                break
+        rollout_mask = self.create_inference_mask(rollouts)
+        return rollouts.masked_fill(~rollout_mask, self.decoder.pad_idx), rollout_log_probs.masked_fill(~rollout_mask, 0.0), rollout_mask
 
     def prepare_rollouts_for_policy_theta(self, rollouts, rollout_mask):
         rollout_lens = rollout_mask.sum(dim=-1, keepdim=True)

@@ -585,30 +585,100 @@ def _mae_prepare(mae, x, noises):
     return imgs, dims, keep, restore, smask, kept
 
 
+def _mae_embed(enc, imgs, dims, keep, prec):
+    """Kept patches -> projection + pos_embedding rows (models.py:153-161), packed.  A projection that is not an nn.Linear (the reference's
+    tests swap in nn.Identity, tests/test_mae.py:61) is the caller's module and is simply called on the fp32 patch rows."""
+    patches, _, _ = _patches(enc, imgs, prec if isinstance(enc.projection, torch.nn.Linear) else "fp32", select=keep)
+    pe = _pe_rows(enc, enc.pos_embedding, dims, select=keep)
+    if isinstance(enc.projection, torch.nn.Linear):
+        return LinearFn.apply(patches, enc.projection.weight, enc.projection.bias, pe, prec, _wc(enc), True)
+    return enc.projection(patches) + pe
+
+
+def _projection_of_padding(enc):
+    """What a zero-padded patch row becomes in the reference's batchify: projection(0) + 0 (models.py:155-161), i.e. the bias."""
+    if isinstance(enc.projection, torch.nn.Linear):
+        return None if enc.projection.bias is None else enc.projection.bias.detach()
+    with torch.no_grad():
+        return enc.projection(torch.zeros(1, enc.patch_size ** 2, device=enc._device())).reshape(-1)
+
+
 def _mae_encode(mae, imgs, dims, keep, kept, prec):
     enc = mae.encoder
-    wc = _wc(enc)
-    patches, _, _ = _patches(enc, imgs, prec, select=keep)
-    pe = _pe_rows(enc, enc.pos_embedding, dims, select=keep)
-    x32 = LinearFn.apply(patches, enc.projection.weight, enc.projection.bias, pe, prec, wc, True)
+    x32 = _mae_embed(enc, imgs, dims, keep, prec)
     cu = EG.cu_from_lens(kept, x32.device)
-    return encoder_stack(enc.encoder_blocks, x32, cu, max(kept), enc._num_heads(), prec, wc, training=enc.training)
+    return encoder_stack(enc.encoder_blocks, x32, cu, max(kept), enc._num_heads(), prec, _wc(enc), training=enc.training)
+
+
+class _EncShim:
+    def __init__(self, enc):
+        self.encoder = enc
+
+
+def mae_mask_sequence(enc, t, h_p, w_p, noise=None):
+    """MAEEncoder.mask_sequence (models.py:106-125): t is ONE unfolded image (1, C P^2, L).  Returns the reference's 6-tuple
+    (t_masked (1, C P^2, L_keep), pos_embed_slice (L_keep, E), L, L_keep, seq_mask (L,) int32 in original order, ids_restore (L,))."""
+    n = t.shape[-1]
+    ids_keep, ids_restore, seq_mask, len_keep = enc.mask_ids(n, t.device, noise)
+    t_masked = t.index_select(dim=-1, index=ids_keep)      # pure data movement of the caller's tensor, any dtype
+    pe = _pe_rows(enc, enc.pos_embedding, [(h_p, w_p)], select=[ids_keep])
+    return t_masked, pe, n, len_keep, seq_mask, ids_restore
+
+
+def mae_encoder_batchify(enc, x, noises=None):
+    """MAEEncoder.batchify (models.py:128-173): the reference's 8-tuple.  Padded rows of `embeddings` hold projection(0), as the reference's
+    pad-then-project order leaves them."""
+    imgs, dims, keep, restore, smask, kept = _mae_prepare(_EncShim(enc), x, noises)
+    x32 = _mae_embed(enc, imgs, dims, keep, _prec())
+    lens = [h * w for h, w in dims]
+    emb, enc_mask = pad_rows(x32, kept, _projection_of_padding(enc))
+    dec_mask = enc.create_attention_mask(lens, max(lens)).to(x32.device)
+    seq_masks = torch.nested.as_nested_tensor(smask, layout=torch.jagged)
+    ids_restore = torch.nested.as_nested_tensor(restore, layout=torch.jagged)
+    return emb, enc_mask, dec_mask, kept, lens, seq_masks, ids_restore, dims
 
 
 def mae_encoder_forward(enc, x, noises=None):
     """MAEEncoder.forward (models.py:176-180) with the reference's return tuple (padded latent, masks, lens, jagged tensors)."""
     _check_dropout(enc)
-
-    class _Shim:
-        encoder = enc
-    imgs, dims, keep, restore, smask, kept = _mae_prepare(_Shim, x, noises)
-    lat = _mae_encode(_Shim, imgs, dims, keep, kept, _prec())
+    imgs, dims, keep, restore, smask, kept = _mae_prepare(_EncShim(enc), x, noises)
+    lat = _mae_encode(_EncShim(enc), imgs, dims, keep, kept, _prec())
     lens = [h * w for h, w in dims]
     padded, _ = pad_rows(lat, kept)
     dec_mask = enc.create_attention_mask(lens, max(lens)).to(lat.device)
     seq_masks = torch.nested.as_nested_tensor(smask, layout=torch.jagged)
     ids_restore = torch.nested.as_nested_tensor(restore, layout=torch.jagged)
     return padded, dec_mask, kept, lens, seq_masks, ids_restore, dims
+
+
+def _restore_rows(mae, lat, kept, lens, restore, dims):
+    """[kept tokens | mask tokens] unshuffled by ids_restore + decoder PE on the packed stream (models.py:219-241): one row gather whose table
+    is the packed latent plus ONE mask-token row (the reference materialises N - keep copies of it per image)."""
+    D = mae.decoder_hidden_dim
+    table = torch.cat([lat, mae.mask_token.reshape(1, D)], 0)
+    Mk = lat.shape[0]
+    idx, o = [], 0
+    for k, n, r in zip(kept, lens, restore):
+        idx.append(torch.where(r < k, r + o, Mk))   # on the device: no host round trip per image
+        o += k
+    dpe = _pe_rows(mae.encoder, mae.decoder_pos_embedding, dims)
+    return GatherRowsFn.apply(table, torch.cat(idx).to(torch.int32), dpe, Mk)   # ids_restore is a permutation: only the mask-token row repeats
+
+
+def mae_prepare_for_decoder(mae, latent, kept_seq_lens, unmasked_seq_lens, batch_ids_restore, patchified_dims):
+    """MAE.prepare_for_decoder (models.py:219-241): padded latent (B, L_keep_max, D) -> padded, positionally embedded decoder input
+    (B, L_max, D); padded rows are zero."""
+    dev = mae.decoder_pos_embedding.device
+    B = latent.shape[0]
+    kept = [int(k) for k in kept_seq_lens]
+    lens = [int(n) for n in unmasked_seq_lens]
+    latent = latent.to(device=dev, dtype=torch.float32)
+    Lk = latent.shape[1]
+    rows = torch.cat([torch.arange(b * Lk, b * Lk + k, dtype=torch.int32) for b, k in enumerate(kept)]).to(dev)
+    lat = GatherRowsFn.apply(latent.reshape(B * Lk, -1), rows, None)          # remove padding (models.py:225)
+    restore = [batch_ids_restore[i].to(dev) for i in range(B)]
+    x32 = _restore_rows(mae, lat, kept, lens, restore, [tuple(d) for d in patchified_dims])
+    return pad_rows(x32, lens)[0]
 
 
 def mae_decoder_forward(dec, x, attention_mask):
@@ -632,16 +702,7 @@ def mae_forward(mae, batch, noises=None, packed=False):
     lat = _mae_encode(mae, imgs, dims, keep, kept, prec)
     wc = _wc(mae)
     lat = _lin(lat, mae.decoder_embed.weight, mae.decoder_embed.bias, prec, wc, out_fp32=True)
-    # prepare_for_decoder (models.py:219-241): [kept tokens | mask tokens] unshuffled by ids_restore, + decoder PE
-    D = mae.decoder_hidden_dim
-    table = torch.cat([lat, mae.mask_token.reshape(1, D)], 0)
-    Mk = lat.shape[0]
-    idx, o = [], 0
-    for k, n, r in zip(kept, lens, restore):
-        idx.append(torch.where(r < k, r + o, Mk))   # on the device: no host round trip per image
-        o += k
-    dpe = _pe_rows(mae.encoder, mae.decoder_pos_embedding, dims)
-    x32 = GatherRowsFn.apply(table, torch.cat(idx).to(torch.int32), dpe, Mk)   # ids_restore is a permutation: only the mask-token row repeats
+    x32 = _restore_rows(mae, lat, kept, lens, restore, dims)   # prepare_for_decoder on the packed stream
     cu = EG.cu_from_lens(lens, dev)
     H = mae.decoder.decoder_blocks.layers[0].self_attn.num_heads
     x32 = encoder_stack(mae.decoder.decoder_blocks, x32, cu, max(lens), H, prec, _wc(mae.decoder), training=mae.training)
