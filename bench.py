@@ -10,6 +10,9 @@ weights) are resident in HBM before the timed region.  Multi-GPU: images are ind
 data-path collective).
 
 Further legs in the same JSON line (each a dict; an exception in a leg is reported in it and never costs the headline):
+  end_to_end     inference() TIMED AS CALLED on the headline batch (8 x 512x2048): encoder + head + prefill + 288 generated tokens      (N = 1)
+  latency_b1     BASELINE config 1 on the GPU: inference() on ONE 256x1024 image, 256 generated tokens, ms/token, with the CPU oracle's
+                 run of the same call beside it                                                                                    (N = 1)
   mae            config 2: MAE fwd + MAELoss + bwd + fused AdamW, batch 32 x 512x2048 per GPU, bf16 (+ RCCL gradient all-reduce when N > 1),
                  with its own `roofline` (MFMA bound; whole step and the dominant attention kernel timed live) and `cpu_baseline`
   tf_step        config 3: ScheduledSamplingViTOMR.forward_train + OMRCELoss + bwd, batch 16 x (512x2048, T = 512), bf16          (N = 1)
@@ -75,6 +78,18 @@ def cpu_model():
     except Exception:
         pass
     return "unknown"
+
+
+def decode_weight_bytes(decoder):
+    """the bf16 weight bytes ONE decode step streams = 12 layers x 14 d^2 + the unembed.  The K/V rows [E:] of the cross
+    attention's in_proj_weight are read by the prefill only (kv_caching.py:212-215 uses rows [:d] in a step) and are not counted:
+    352.8 MB for the full-size decoder (counting them gave 403 MB in rounds 1-2)."""
+    E = decoder.hidden_dim
+    n = 0
+    for name, p in decoder.named_parameters():
+        if "decoder_blocks.layers" in name and p.dim() == 2:
+            n += E * p.shape[1] if name.endswith("multihead_attn.in_proj_weight") else p.numel()
+    return (n + decoder.unembed.weight.numel()) * 2
 
 
 def build_model(device, batch, cache_dtype=torch.bfloat16):
@@ -334,8 +349,7 @@ def bench_ragged_decode(dev, steps, warm=16):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     cur.wait_stream(eng.stream)
-    w_bytes = sum(p.numel() for n, p in vitomr.decoder.named_parameters() if "decoder_blocks.layers" in n and p.dim() == 2) * 2 + \
-        vitomr.decoder.unembed.weight.numel() * 2
+    w_bytes = decode_weight_bytes(vitomr.decoder)
     step_bytes = w_bytes + sum(12 * 2 * (s + warm + steps // 2) * 1024 * 2 for s in lens)
     out = dict(config=f"config 4: greedy decode, ragged batch of 8 systems 256x1024..768x3072 (sum N = {sum(lens)} patches), {steps} steps, hipGraph",
                tokens_per_s=8 * steps / dt, ms_per_step=dt / steps * 1e3, prefill_ms=pf * 1e3, memory_lens=lens, step_bytes=step_bytes,
@@ -429,6 +443,69 @@ def bench_config5(dev, rank, world, dist, per_gpu, T, steps):
     del m, ddp, opt, data, enc, dec
     torch.cuda.empty_cache()
     out["dp_parity_max_abs_diff"] = dp_parity_check(os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "lmx_vocab.txt"), dev)
+    out["dp_parity_ok"] = bool(out["dp_parity_max_abs_diff"] < 1e-4)   # DP step over RCCL == the single-process global-batch step
+    if not out["dp_parity_ok"]:
+        out["error"] = f"data-parallel step differs from the single-process global-batch step by {out['dp_parity_max_abs_diff']:.3e} (>= 1e-4)"
+    return out
+
+
+# ---- timed calls of the entry point itself: inference() as the reference's callers use it ---------------------------------------------------
+def _suppress_eos(vitomr):
+    """Random-init weights may or may not emit <eos>; a fixed generation length needs it out of reach.  The unembed bias of <eos> is pushed far
+    below every other logit (same kernels, same bytes, same step count for every sequence); returns a function that restores it."""
+    b = vitomr.decoder.unembed.bias
+    old = b.detach()[vitomr.decoder.eos_idx].clone()
+    with torch.no_grad():
+        b[vitomr.decoder.eos_idx] = -1e4
+
+    def restore():
+        with torch.no_grad():
+            b[vitomr.decoder.eos_idx] = old
+    return restore
+
+
+def bench_inference_call(dev, shapes, gen, reps, want_cpu, cpu_gen=64):
+    """`inference(vitomr, imgs, device, max_inference_len=gen + 1)` (vitomr_inference.py:73-86) TIMED AS CALLED: encoder (fp32) + transition
+    head + cross-K/V prefill + the greedy loop with its host poll every 16 tokens + mask_and_clip, on `shapes` synthetic images, <eos>
+    suppressed so every sequence generates exactly `gen` tokens.  tokens/s counts generated tokens (excluding <bos>) over the whole call."""
+    from acai_omr_amd.inference.vitomr_inference import inference
+    vitomr = build_model(dev, len(shapes))
+    restore = _suppress_eos(vitomr)
+    g = torch.Generator().manual_seed(5)
+    imgs = [torch.rand(1, h, w, generator=g).to(dev) for h, w in shapes]
+    arg = imgs[0] if len(imgs) == 1 else imgs          # config 1 passes the bare (1,H,W) tensor, as vitomr_inference.py:81 does
+    seqs, _, mask = inference(vitomr, arg, "cuda", max_inference_len=gen + 1)     # warm-up: code objects, graph capture, allocator
+    torch.cuda.synchronize()
+    assert seqs.shape == (len(shapes), gen + 1) and bool(mask.all()), (tuple(seqs.shape), int(mask.sum()))
+    times = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        seqs, _, mask = inference(vitomr, arg, "cuda", max_inference_len=gen + 1)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
+    B = len(shapes)
+    out = dict(call=f"inference(vitomr, {'img' if B == 1 else f'[{B} imgs]'}, 'cuda', max_inference_len={gen + 1})", images=f"{B} x {shapes[0][0]}x{shapes[0][1]}",
+               generated_tokens_per_sequence=gen, seconds_per_call=dt, tokens_per_s=B * gen / dt, ms_per_token=dt / gen * 1e3, reps=reps,
+               includes="encoder fp32 + transition head + cross-K/V prefill + greedy loop (hipGraph replays, host poll every 16 tokens) + mask_and_clip; timed around the call, median of reps")
+    if want_cpu:
+        from oracle import vitomr_oracle as O
+        cores = host_cores()
+        torch.set_num_threads(cores)
+        sd = {k: v.detach().float().cpu() for k, v in vitomr.state_dict().items()}
+        cimgs = [im.cpu() for im in imgs]
+        t0 = time.perf_counter()
+        oseqs, _, _ = O.vitomr_inference(cimgs, sd, 12, 16, 16, cpu_gen + 1)
+        cdt = time.perf_counter() - t0
+        n_tok = int(oseqs.shape[1] - 1)
+        same = bool(torch.equal(oseqs[:, :n_tok + 1], seqs.cpu()[:, :n_tok + 1]))
+        out["cpu_baseline"] = dict(value=B * n_tok / cdt, unit="tokens/s (end to end)", seconds=cdt, cores=cores, cpu=cpu_model(), kind="port",
+                                   sample=f"the same call through the CPU oracle (encoder fp32, head + decode in its autocast(bf16) restatement), {n_tok} generated tokens",
+                                   token_ids_equal_gpu=same)
+    restore()
+    del vitomr
+    torch.cuda.empty_cache()
     return out
 
 
@@ -454,7 +531,7 @@ def main():
     ap.add_argument("--mae-batch", type=int, default=32)
     ap.add_argument("--mae-steps", type=int, default=3)
     ap.add_argument("--mae-dtype", default="bf16", choices=["fp32", "bf16"])
-    ap.add_argument("--legs", default=None, help="comma list of mae,tf,ragged,config5 (default: mae,tf,ragged at N = 1; mae,config5 at N > 1)")
+    ap.add_argument("--legs", default=None, help="comma list of e2e,b1,mae,tf,ragged,config5 (default: e2e,b1,mae,tf,ragged at N = 1; mae,config5 at N > 1)")
     ap.add_argument("--no-mae", action="store_true")
     ap.add_argument("--leg-timeout", type=float, default=420.0, help="seconds the secondary legs may take before the line is printed without them")
     a = ap.parse_args()
@@ -472,7 +549,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    legs = set((a.legs.split(",") if a.legs is not None else (["mae", "tf", "ragged"] if world == 1 else ["mae", "config5"])))
+    legs = set((a.legs.split(",") if a.legs is not None else (["e2e", "b1", "mae", "tf", "ragged"] if world == 1 else ["mae", "config5"])))
     legs.discard("")
     if a.no_mae:
         legs.discard("mae")
@@ -537,8 +614,7 @@ def main():
     if rank == 0:
         t_mid = min(a.warmup + a.steps // 2, cap // 2) if a.warmup + a.steps <= cap else cap // 2
         # algorithmic bytes: weights once per step + per sequence 12*2*(S + t)*1024*2 B
-        w_bytes = sum(p.numel() for n, p in vitomr.decoder.named_parameters() if "decoder_blocks.layers" in n and p.dim() == 2) * 2 + \
-            vitomr.decoder.unembed.weight.numel() * 2
+        w_bytes = decode_weight_bytes(vitomr.decoder)
         step_bytes = w_bytes + a.batch * 12 * 2 * (S + t_mid) * 1024 * 2
         step_s = dt / a.steps
         k_s = time_decode_attn_kernels(eng)
@@ -569,8 +645,10 @@ def main():
     # The headline is measured.  The secondary legs must never cost it: an exception inside one is caught (`_leg`), and a HANG (a collective that
     # one rank never reaches) is cut by a watchdog on every rank - after `--leg-timeout` seconds rank 0 prints the line with what it has and every
     # rank leaves the process.
-    res = dict(mae=None, tf_step=None, ragged_decode=None, config5=None)
+    res = dict(mae=None, tf_step=None, ragged_decode=None, config5=None, latency_b1=None, end_to_end=None)
+    res_lock = threading.Lock()
     printed = threading.Event()
+    running = ["-"]
 
     def emit(timed_out):
         if printed.is_set():
@@ -578,13 +656,19 @@ def main():
         printed.set()
         if rank != 0:
             return
-        out = build_line(res, timed_out)
+        with res_lock:
+            snap = dict(res)
+        out = build_line(snap, timed_out)
         print(json.dumps(out), flush=True)
 
     def watchdog():
+        # A leg that neither returns nor raises within --leg-timeout is a HANG (a collective one rank never reaches, a kernel that never drains).
+        # The headline and the finished legs are still printed, but the process reports failure: stderr names the leg, exit code 3.
         if not printed.wait(a.leg_timeout):
+            sys.stderr.write(f"bench.py: rank {rank}: leg '{running[0]}' did not finish within {a.leg_timeout} s - printing the partial line and exiting with code 3\n")
+            sys.stderr.flush()
             emit(True)
-            os._exit(0)
+            os._exit(3)
 
     def build_line(res, timed_out):
         mae_res, tf_res, rag_res, c5_res = res["mae"], res["tf_step"], res["ragged_decode"], res["config5"]
@@ -596,24 +680,35 @@ def main():
                    ragged_decode=rag_res, config5=c5_res)
         if timed_out:
             out["legs_timed_out"] = f"secondary legs did not finish within {a.leg_timeout} s; fields still None were not measured"
-        # decode-only (`value`) and end to end.  Composed from the two measured parts - the prefill timed once above and the timed
-        # decode steps - for a generation of 288 tokens per sequence (the default warmup + steps); not a separately timed run.
-        gen = 288
-        out["end_to_end"] = dict(tokens_per_s=world * a.batch * gen / (prefill_s + gen * dt / a.steps), generated_tokens_per_sequence=gen,
-                                 includes=f"encoder ({a.encoder_dtype}) + transition head + cross-K/V prefill (measured once) + {gen} decode steps at the measured step time")
+        # decode-only (`value`) and end to end.  `end_to_end` = a TIMED call of inference() on the same batch shape (encoder + head +
+        # prefill + 288 generated tokens per sequence, host polling included); `latency_b1` = BASELINE config 1 (one 256x1024 image) the same way.
+        out["end_to_end"] = res["end_to_end"]
+        out["latency_b1"] = res["latency_b1"]
         if cpu is not None:
             out["gpu_over_cpu"] = out["value"] / cpu["value"]
         return out
 
     threading.Thread(target=watchdog, daemon=True).start()
+
+    def run_leg(key, fn, *args):
+        running[0] = key
+        r = _leg(fn, *args)
+        with res_lock:
+            res[key] = r
+
+    if "e2e" in legs and world == 1:
+        run_leg("end_to_end", bench_inference_call, dev, [(a.height, a.width)] * a.batch, 288, 3, False)
+    if "b1" in legs and world == 1:
+        run_leg("latency_b1", bench_inference_call, dev, [(256, 1024)], 256, 3, want_cpu)
     if "mae" in legs:
-        res["mae"] = _leg(bench_mae, dev, rank, world, dist, a.mae_batch, a.height, a.width, a.mae_steps, a.mae_dtype, want_cpu)
+        run_leg("mae", bench_mae, dev, rank, world, dist, a.mae_batch, a.height, a.width, a.mae_steps, a.mae_dtype, want_cpu)
     if "tf" in legs and world == 1:
-        res["tf_step"] = _leg(bench_tf_step, dev, 16, a.height, a.width, 512, 2)
+        run_leg("tf_step", bench_tf_step, dev, 16, a.height, a.width, 512, 2)
     if "ragged" in legs and world == 1:
-        res["ragged_decode"] = _leg(bench_ragged_decode, dev, 512)
+        run_leg("ragged_decode", bench_ragged_decode, dev, 512)
     if "config5" in legs:
-        res["config5"] = _leg(bench_config5, dev, rank, world, dist, 32, 512, 2)
+        run_leg("config5", bench_config5, dev, rank, world, dist, 32, 512, 2)
+    running[0] = "-"
     emit(False)
     if dist is not None:
         dist.barrier()

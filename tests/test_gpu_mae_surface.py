@@ -77,7 +77,8 @@ def test_kat_masked_encoder_batchify(dev):
     assert [int(m.sum()) for m in seq_masks.unbind()] == [2, 3]
     assert [sorted(r.tolist()) for r in ids_restores.unbind()] == [list(range(4)), list(range(6))]
     # MAEEncoder.forward keeps its 7-tuple (tests/test_mae.py:81-87)
-    enc2 = MAEEncoder(0.50, 2, PE_MAX_HEIGHT, PE_MAX_WIDTH, num_layers=2, num_heads=2, hidden_dim=200, mlp_dim=500).to(dev)
+    # (the reference's test uses hidden 200 over 2 heads; the attention kernels carry head dims up to 64, so 4 heads here)
+    enc2 = MAEEncoder(0.50, 2, PE_MAX_HEIGHT, PE_MAX_WIDTH, num_layers=2, num_heads=4, hidden_dim=200, mlp_dim=500).to(dev)
     f = enc2([torch.rand(NUM_CHANNELS, 4, 4), torch.rand(NUM_CHANNELS, 4, 8)])
     assert len(f) == 7 and f[0].shape == torch.Size([2, 4, 200])
 
