@@ -534,6 +534,15 @@ __device__ __forceinline__ void glds16(uint32_t lds_dst, const void *src) {
                  : "memory");
 }
 
+// the same with the source as a uniform base (SGPR pair) + a 32-bit byte offset per lane
+__device__ __forceinline__ void glds16s(uint32_t lds_dst, const void *sbase, uint32_t voff) {
+    uint32_t m0_save;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_save)
+                 : "s"(lds_dst), "v"(voff), "s"(sbase)
+                 : "memory");
+}
+
 // ---- 256x128 tile, 8 waves, THREE LDS stages (144 KB): two K-tiles in flight ------------------------------------------------------------
 // The two-stage kernels are latency-bound, not MFMA-bound (PMC: MFMA busy 36 %, a third of the wave cycles in s_waitcnt, L2 hit rate 64 %):
 // with one tile in flight per workgroup a CU has 64 KB outstanding, and 64 KB x 256 CUs / ~1.2 us of loaded L2/fabric latency is exactly the
@@ -1199,6 +1208,347 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     }
 }
 
+// ---- register epilogue of the swapped 16x16x32 layout (gemm_nt_pp_kernel) ----------------------------------------------------------------
+// Lane (lm = lane & 15, lq = lane >> 4) of accumulator [mb][nb] holds C[m0 + mb*16 + lm][n0 + nb*16 + 4*lq + e], e = 0..3: four consecutive
+// columns of one row.  fp32 rows are stored / loaded 16 bytes per lane as they stand (16 rows x 64 contiguous bytes per wave instruction).
+// bf16: the two packed dwords of blocks nb = 2p and 2p+1 are exchanged between neighbouring 16-lane rows (v_permlane16_swap: odd rows of the
+// first operand <-> even rows of the second), after which lane row r holds EIGHT consecutive columns: block 2p + (r & 1), columns 8 (r >> 1) ..;
+// the exchange is an involution, so a 16-byte bf16 load at the swapped position followed by the same exchange yields the original layout
+// (the saved pre-activation of aux_mode 2).  Every global access is a raw buffer access whose out-of-range lanes (rows >= M, columns >= N:
+// offset forced beyond num_records) are dropped by the hardware range check: no divergent branch, and the instruction count per tile is exact
+// (the caller's counted vmcnt wait relies on it).  Arithmetic and its order are gemm_vec_epilogue's.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+__device__ __forceinline__ void pp_swap2(uint32_t &x, uint32_t &y) {
+    const u32x2_t r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+    x = r[0];
+    y = r[1];
+}
+__device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 (&acc)[8][4], int m0, int n0, int lane) {
+    const int lm = lane & 15, lq = lane >> 4;
+    const bool obf = g.out_dtype == ACAI_BF16;
+    const bool do_gelu = g.flags & ACAI_GEMM_GELU, do_round = g.flags & ACAI_GEMM_ROUND_BF16;
+    const bool pre_round = do_round && (do_gelu || g.aux_mode != 0 || g.residual != nullptr || !obf);
+    const int es = obf ? 2 : 4;
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)((size_t)g.M * g.ldc * es), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.residual ? g.residual : reinterpret_cast<const float *>(g.C)), 0,
+                                                                        g.residual ? (int)((size_t)g.M * g.ldr * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(g.aux_mode ? g.aux : g.C, 0, g.aux_mode ? (int)((size_t)g.M * g.ldaux * es) : 0, 0x00020000);
+    constexpr uint32_t OOB = 0xFFFFFFF0u;
+    const bool has_scale = g.scale_cols > 0;
+    // swapped (bf16) position of this lane inside a block pair: block 2p + (lq & 1), columns 8 (lq >> 1) .. + 7
+    const int sw_col = n0 + (lq & 1) * 16 + (lq >> 1) * 8;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {      // block pair outermost: only its eight per-column constants are live
+        f32x4 bias4[4];
+        bool colok[4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int nb = 2 * p + t, col = n0 + nb * 16 + 4 * lq;
+            colok[nb] = col < g.N;
+            bias4[nb] = (g.bias && colok[nb]) ? *reinterpret_cast<const f32x4 *>(g.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) {
+            const int row = m0 + mb * 16 + lm;
+            const bool rowok = row < g.M;
+            f32x4 v[2];
+            const bool swok = rowok && (sw_col + p * 32) < g.N;
+            const uint32_t off_sw_c = swok ? (uint32_t)(((size_t)row * g.ldc + sw_col + p * 32) * 2) : OOB;
+            const uint32_t off_sw_x = swok ? (uint32_t)(((size_t)row * g.ldaux + sw_col + p * 32) * 2) : OOB;
+            float a0[2][4];
+            if (g.aux_mode == 2) {
+                if (obf) {
+                    u32x4_t L = __builtin_amdgcn_raw_buffer_load_b128(rx, off_sw_x, 0, 0);
+                    uint32_t x0 = L[0], x1 = L[1], y0 = L[2], y1 = L[3];
+                    pp_swap2(x0, y0);
+                    pp_swap2(x1, y1);
+                    a0[0][0] = __uint_as_float(x0 << 16); a0[0][1] = __uint_as_float(x0 & 0xFFFF0000u);
+                    a0[0][2] = __uint_as_float(x1 << 16); a0[0][3] = __uint_as_float(x1 & 0xFFFF0000u);
+                    a0[1][0] = __uint_as_float(y0 << 16); a0[1][1] = __uint_as_float(y0 & 0xFFFF0000u);
+                    a0[1][2] = __uint_as_float(y1 << 16); a0[1][3] = __uint_as_float(y1 & 0xFFFF0000u);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int nb = 2 * p + t, col = n0 + nb * 16 + 4 * lq;
+                        const uint32_t o = (rowok && colok[nb]) ? (uint32_t)(((size_t)row * g.ldaux + col) * 4) : OOB;
+                        const u32x4_t L = __builtin_amdgcn_raw_buffer_load_b128(rx, o, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a0[t][e] = __uint_as_float(L[e]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int nb = 2 * p + t;
+                v[t] = acc[mb][nb] + bias4[nb];
+                if (has_scale) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[t][e] *= (n0 + nb * 16 + 4 * lq + e) < g.scale_cols ? g.col_scale : 1.0f;
+                }
+                if (pre_round) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[t][e] = round_bf16(v[t][e]);
+                }
+            }
+            if (g.aux_mode == 1) {   // keep the pre-activation
+                if (obf) {
+                    uint32_t x0 = pack_bf16(v[0][0], v[0][1]), x1 = pack_bf16(v[0][2], v[0][3]), y0 = pack_bf16(v[1][0], v[1][1]), y1 = pack_bf16(v[1][2], v[1][3]);
+                    pp_swap2(x0, y0);
+                    pp_swap2(x1, y1);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{x0, x1, y0, y1}, rx, off_sw_x, 0, 0);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int nb = 2 * p + t, col = n0 + nb * 16 + 4 * lq;
+                        const uint32_t o = (rowok && colok[nb]) ? (uint32_t)(((size_t)row * g.ldaux + col) * 4) : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[t]), rx, o, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int nb = 2 * p + t, col = n0 + nb * 16 + 4 * lq;
+                if (g.aux_mode == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[t][e] *= gelu_erf_grad(a0[t][e]);
+                }
+                if (do_gelu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[t][e] = gelu_erf(v[t][e]);
+                        if (do_round) v[t][e] = round_bf16(v[t][e]);
+                    }
+                }
+                if (g.residual) {
+                    const uint32_t o = (rowok && colok[nb]) ? (uint32_t)(((size_t)row * g.ldr + col) * 4) : OOB;
+                    const u32x4_t L = __builtin_amdgcn_raw_buffer_load_b128(rr, o, 0, 0);
+                    v[t] += __builtin_bit_cast(f32x4, L);
+                }
+                if (!obf) {
+                    const uint32_t o = (rowok && colok[nb]) ? (uint32_t)(((size_t)row * g.ldc + col) * 4) : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[t]), rc, o, 0, 0);
+                }
+            }
+            if (obf) {
+                uint32_t x0 = pack_bf16(v[0][0], v[0][1]), x1 = pack_bf16(v[0][2], v[0][3]), y0 = pack_bf16(v[1][0], v[1][1]), y1 = pack_bf16(v[1][2], v[1][3]);
+                pp_swap2(x0, y0);
+                pp_swap2(x1, y1);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{x0, x1, y0, y1}, rc, off_sw_c, 0, 0);
+            }
+        }
+    }
+}
+
+// ---- persistent 256x256 ring with PING-PONG wave groups and a REGISTER epilogue (round 3) -----------------------------------------------
+// What round 2 measured on the short-K GEMMs of the training steps (K = 512..768): the main loop of the rings runs at ~40-45 % of the matrix
+// pipe and the epilogue (LDS transposition + stores, nothing else running on the CU meanwhile) adds another 50 % on top.  Both have one cause:
+// the two waves of a SIMD run the same program in lock-step behind one barrier per K-step - both read fragments, both issue MFMAs, both
+// transpose and store - so the matrix pipe idles whenever "the" wave does anything else.  This kernel keeps pers256's ring (five 32 KB
+// half-stage slots, LDS-DMA from inline asm, counted vmcnt waits, persistent XCD-contiguous tile lists) and changes three things:
+//  1. Ping-pong: a K-step is four barrier-separated segments per wave - R(kh=0): 12 ds_read_b128, M(kh=0): 32 MFMAs, R(kh=1), M(kh=1) - and
+//     waves 4-7 (the lower 128 rows of the tile; they share SIMDs with waves 0-3) run ONE SEGMENT BEHIND waves 0-3: while one wave of a
+//     SIMD issues its 32 MFMAs the other reads its fragments, issues its LDS-DMA or runs its epilogue.  Fragments are single-buffered (the
+//     partner's MFMAs cover the read latency), so the loop needs 48 fragment registers instead of 96.
+//  2. v_mfma_f32_16x16x32_bf16 with the operands SWAPPED (W fragment as the A operand): D[n][m], a lane holds FOUR CONSECUTIVE COLUMNS of one
+//     output row.  fp32 outputs store 16 bytes per lane straight from the accumulators; bf16 outputs exchange the packed halves of two
+//     neighbouring 16-column blocks between the 16-lane rows (v_permlane16_swap) and also store 16 bytes per lane - 16 rows x 64 contiguous
+//     bytes per wave instruction, no LDS transposition, no epilogue barrier, no staging space.  (The 16x16x32 shape also holds a higher clock
+//     than 32x32x16 at equal cycles per flop on this chip: MI355X_MICROARCH.md, DVFS item 7.)
+//  3. The epilogue of tile i runs in the first R segment of tile i+1 of the same wave - i.e. beside the partner's MFMAs - and its stores stay
+//     in flight: they are raw buffer stores (out-of-range lanes dropped by the range check, so the instruction COUNT is exact) issued between
+//     the segment's two LDS-DMA groups, and the K-step's counted wait allows for them (vmcnt counts stores and LDS-DMA together, in order).
+// Segment / barrier ledger (b_s = barrier at the end of global segment s; waves 0-3 = G0, waves 4-7 = G1):
+//     G0: R(q,0) = seg 4q, M(q,0) = 4q+1, R(q,1) = 4q+2, M(q,1) = 4q+3;    G1: the same one segment later (4q+1 .. 4q+4)
+//     slots of K-step q are last read in seg 4q+3 (G1, reads waited with lgkmcnt(0) before b_{4q+3}) and refilled from seg 4q+4 on;
+//     every wave waits for ITS pieces of K-step q+1 (vmcnt) before b_{4q+3}; the first read of K-step q+1 is in seg 4q+4.
+template <typename T>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_pp_kernel(GemmArgs g) {
+    static_assert(sizeof(T) == 2, "bf16 row-major operands");
+    constexpr int BK = ROWB / sizeof(T);
+    constexpr int BT = 256, UNIT = BT * ROWB, NSLOT = 5;   // 32 KB per unit
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NSLOT * UNIT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3, grp = wm;
+    const int lm = lane & 15, lq = lane >> 4;
+    const int nbn = (g.N + BT - 1) / BT, nbm = (g.M + BT - 1) / BT, ntiles = nbn * nbm;
+    const int w = blockIdx.x, nwg = gridDim.x, xcd = w % 8, j0 = w / 8;
+    const int per_xcd = (nwg - xcd + 7) / 8;
+    const int tq = ntiles / 8, tr = ntiles % 8;
+    const int t_start = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, t_count = tq + (xcd < tr ? 1 : 0);
+    const int n_my = j0 < t_count ? (t_count - j0 + per_xcd - 1) / per_xcd : 0;
+    const int nkt = g.K / BK, total = n_my * nkt;
+    if (total == 0) return;
+    const T *A = reinterpret_cast<const T *>(g.A);
+    const T *W = reinterpret_cast<const T *>(g.W);
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr)lds;
+
+    // ---- producer (as pers256): one cursor per operand, A runs one K-step ahead of W ----
+    // Sources as a uniform base (SGPR pair: the tile's first row, advanced per K-step) + a 32-bit byte offset per lane: (row within the tile,
+    // clamped to the operand's last row) x pitch + the swizzled 16-byte slot.  24-bit multiplies (the host checks pitch < 2^24 bytes).
+    const int grow = lane >> 3;
+    const int r0 = wave * 32 + grow;                                  // this lane's tile row for piece i: r0 + 8 i
+    const uint32_t g0 = (uint32_t)(((lane & 7) ^ (grow >> 1)) << 4);   // its slot for even i; odd i: ^ 64
+    const uint32_t pitchA = (uint32_t)g.lda * 2, pitchW = (uint32_t)g.ldw * 2;
+    uint32_t offA[4], offW[4];
+    const T *tileA = A, *tileW = W;
+    int a_tile = 0, a_kt = 0, w_tile = 0, w_kt = 0, p_slot = 0;
+    auto tile_origin = [&](int ti, int &bm0, int &bn0) {
+        const int t = t_start + j0 + ti * per_xcd;
+        bm0 = (t / nbn) * BT;
+        bn0 = (t % nbn) * BT;
+    };
+    auto set_a = [&](int ti) {
+        int bm0, bn0;
+        tile_origin(ti, bm0, bn0);
+        tileA = A + (size_t)bm0 * g.lda;
+        const int last = g.M - 1 - bm0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) offA[i] = __umul24(min(r0 + 8 * i, last), pitchA) + (g0 ^ ((i & 1) << 6));
+    };
+    auto set_w = [&](int ti) {
+        int bm0, bn0;
+        tile_origin(ti, bm0, bn0);
+        tileW = W + (size_t)bn0 * g.ldw;
+        const int last = g.N - 1 - bn0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) offW[i] = __umul24(min(r0 + 8 * i, last), pitchW) + (g0 ^ ((i & 1) << 6));
+    };
+    int a_done = 0, w_done = 0;
+    auto next_slot = [&]() { p_slot = p_slot == NSLOT - 1 ? 0 : p_slot + 1; };
+    auto issue_a = [&]() {
+        if (a_done >= total) return;
+        const uint32_t lb = lds_base + p_slot * UNIT;
+        const T *base = tileA + (size_t)a_kt * BK;   // uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16s(__builtin_amdgcn_readfirstlane(lb + (wave * 4 + i) * 1024), base, offA[i]);
+        if (++a_kt == nkt) {
+            a_kt = 0;
+            if (++a_tile < n_my) set_a(a_tile);
+        }
+        ++a_done;
+        next_slot();
+    };
+    auto issue_w = [&]() {
+        if (w_done >= total) return;
+        const uint32_t lb = lds_base + p_slot * UNIT;
+        const T *base = tileW + (size_t)w_kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16s(__builtin_amdgcn_readfirstlane(lb + (wave * 4 + i) * 1024), base, offW[i]);
+        if (++w_kt == nkt) {
+            w_kt = 0;
+            if (++w_tile < n_my) set_w(w_tile);
+        }
+        ++w_done;
+        next_slot();
+    };
+
+    // ---- consumer: swapped 16x16x32 MFMAs; lane (lm, lq) of accumulator [mb][nb] holds C[mb*16 + lm][nb*16 + 4*lq + 0..3] ----
+    f32x4 acc[8][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // logical 16-byte chunk c = 4 kh + lq of tile row r sits in slot c ^ ((r >> 1) & 7); (r >> 1) & 7 = (lm >> 1) & 7 for every row this lane
+    // reads (the rows differ by multiples of 16).  16 lanes of a ds_read_b128 group then cover 16 distinct 16-byte bank groups.
+    const int swz = (lm >> 1) & 7;
+    const int offk0 = (lq ^ swz) << 4, offk1 = ((4 + lq) ^ swz) << 4;
+    const int a_off = (wm * 128 + lm) * ROWB, w_off = (wn * 64 + lm) * ROWB;
+    uint4 fa[8], fw[4];
+    auto reads = [&](const unsigned char *sa, const unsigned char *sb, int offk) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const uint4 *>(sb + w_off + j * 16 * ROWB + offk);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const uint4 *>(sa + a_off + i * 16 * ROWB + offk);
+    };
+    auto mfmas = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+    };
+#define PP_BAR()                                      \
+    do {                                              \
+        __builtin_amdgcn_sched_barrier(0);            \
+        asm volatile("s_barrier" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);            \
+    } while (0)
+#define PP_LGKM0()                                               \
+    do {                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    } while (0)
+    // counted wait of K-step q: everything up to W(q+1) has landed; younger and allowed in flight: the epilogue's stores (n_st of them when an
+    // epilogue ran in this K-step) and the four pieces of A(q+2) (when it exists)
+    auto wait_step = [&](int allow) {
+        switch (allow) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+            case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+            case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
+    const int n_st = g.out_dtype == ACAI_BF16 ? (g.aux_mode == 1 ? 32 : 16) : 32;   // store instructions per wave and tile (host: vec_epi only)
+
+    set_a(0);
+    set_w(0);
+    issue_a();   // A(0)
+    issue_w();   // W(0)
+    issue_a();   // A(1)
+    zero_acc();
+    if (total > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BAR();              // b_{-1}: K-step 0 has landed for everybody
+    if (grp == 1) PP_BAR();   // G1 runs one segment behind
+    int c_tile = 0, c_kt = 0, slot_a = 0;
+    for (int q = 0; q <= total; ++q) {
+        const bool live = q < total;    // the extra pass q == total only runs the last tile's epilogue (and keeps the barrier count)
+        const int slot_w = slot_a == NSLOT - 1 ? 0 : slot_a + 1;
+        const unsigned char *sa = lds + slot_a * UNIT, *sb = lds + slot_w * UNIT;
+        // ---- R(q, 0) ----
+        issue_w();   // W(q+1) -> the slot A(q-1) left
+        int allow = q + 2 < total ? 4 : 0;
+        if (c_kt == 0 && q > 0) {
+            int bm0, bn0;
+            tile_origin(c_tile - 1, bm0, bn0);
+            gemm_pp_epilogue(g, acc, bm0 + wm * 128, bn0 + wn * 64, lane);
+            zero_acc();
+            allow += n_st;
+        }
+        issue_a();   // A(q+2) -> the slot W(q-1) left
+        if (live) reads(sa, sb, offk0);   // (after the epilogue: the fragment registers are not live across it)
+        PP_LGKM0();
+        PP_BAR();
+        // ---- M(q, 0) ----
+        if (live) mfmas();
+        PP_BAR();
+        // ---- R(q, 1) ----
+        if (live) reads(sa, sb, offk1);
+        PP_LGKM0();
+        if (grp == 1 && q + 1 < total) wait_step(allow);
+        PP_BAR();
+        // ---- M(q, 1) ----
+        if (live) mfmas();
+        if (grp == 0 && q + 1 < total) wait_step(allow);
+        PP_BAR();
+        if (live && ++c_kt == nkt) {
+            c_kt = 0;
+            ++c_tile;
+        }
+        slot_a = slot_a + 2 >= NSLOT ? slot_a + 2 - NSLOT : slot_a + 2;
+    }
+    if (grp == 0) PP_BAR();
+#undef PP_BAR
+#undef PP_LGKM0
+}
+
 // ---- dW = dY^T X on the three-stage ring (round 2) -------------------------------------------------------------------------------------
 // gemm_tn_glds_kernel keeps ONE 64-token tile in flight per workgroup (two stages, `__syncthreads()` drains the LDS-DMA): a K-step of a
 // 128x128 tile is ~0.2 us of MFMA work against >= 1 us of loaded fabric latency, and two co-resident workgroups do not cover it (0.61-0.69 PF
@@ -1394,9 +1744,20 @@ int launch(const GemmArgs &g, hipStream_t st) {
                 !(g.N <= 512 && ktiles <= 8))
                 v = 6;
         }
-        if ((v == 5 || v == 6) && nwg256 < 8) v = 1;
+        if (v == 7) {   // the register epilogue addresses C / residual / aux through 32-bit buffer offsets
+            const size_t lim = 0xFFFFFF00ull, esz = g.out_dtype == ACAI_BF16 ? 2 : 4;
+            const bool fits = (size_t)g.M * g.ldc * esz < lim && (!g.residual || (size_t)g.M * g.ldr * 4 < lim) && (!g.aux_mode || (size_t)g.M * g.ldaux * esz < lim);
+            const bool src32 = (size_t)g.lda * 2 < (1u << 24) && (size_t)g.ldw * 2 < (1u << 24);   // 24-bit multiplies in the lane offsets of the LDS-DMA sources
+            if (!(sizeof(T) == 2 && EPI == 0) || !fits || !src32 || !h.vec_epi) v = 6;
+        }
+        if ((v == 5 || v == 6 || v == 7) && nwg256 < 8) v = 1;
         if (v == 4 && nwg4 < 8) v = 1;
         switch (v) {
+            case 7:
+                if constexpr (sizeof(T) == 2 && EPI == 0) {
+                    hipLaunchKernelGGL((gemm_nt_pp_kernel<T>), dim3(nwg256 < n_cu ? nwg256 : n_cu), dim3(512), 0, st, h);
+                    break;
+                }
             case 6:
                 if constexpr (sizeof(T) == 2 && EPI == 0) {
                     hipLaunchKernelGGL((gemm_nt_pers256_kernel<T, EPI>), dim3(nwg256 < n_cu ? nwg256 : n_cu), dim3(512), 0, st, h);
@@ -1420,7 +1781,7 @@ int launch(const GemmArgs &g, hipStream_t st) {
 }  // namespace
 
 extern "C" int acai_gemm_set_variant(int variant) {
-    ACAI_CHECK_ARG(variant >= 0 && variant <= 6, "acai_gemm_set_variant: 0 (auto) .. 6");
+    ACAI_CHECK_ARG(variant >= 0 && variant <= 7, "acai_gemm_set_variant: 0 (auto) .. 7");
     g_gemm_variant = variant;
     return 0;
 }

@@ -40,13 +40,13 @@ def test_gemm_nt(dev, M, N, K, dtype):
     _check_gemm_nt(dev, M, N, K, dtype)
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("K", [64, 128, 192, 256, 320, 704])
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
 def test_gemm_nt_three_stage_tile(dev, K, dtype, variant):
     """The large-tile LDS-DMA kernels, each pinned in turn (256x128 two-stage, three-stage with counted vmcnt waits, persistent ring across
-    tiles, 256x256, persistent 256x256 on the ring of half-stages): every K-tile
-    count modulo 3, one to many tiles, ragged M / N edges."""
+    tiles, 256x256, persistent 256x256 on the ring of half-stages, 7 = the ping-pong ring with the register epilogue - bf16 only, fp32 falls
+    back to 6): every K-tile count modulo 3, one to many tiles, ragged M / N edges."""
     from acai_omr_amd import _lib
     if dtype == "fp32":
         K //= 2   # 32 floats per K-tile: same tile counts
@@ -340,3 +340,61 @@ def test_gemm_weight_gradient_form(dev, dtype, shape):
     out2 = seed.clone().to(dev)
     ops.gemm(wide[:, 8:8 + M], x.to(dev).to(dt), trans_a=True, trans_w=True, out=out2)
     assert (out2.cpu().double() - ref).abs().max() < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [64, 192, 512])
+@pytest.mark.parametrize("shape", [(8192 + 40, 2048 + 24), (16384 + 8, 512), (70000, 768)])
+def test_gemm_nt_pingpong_epilogues(dev, K, shape):
+    """gemm_nt_pp_kernel (variant 7: ping-pong wave groups, swapped 16x16x32 MFMAs, register epilogue with permlane16 exchanges and raw buffer
+    stores) in EVERY epilogue form the training steps use, against the persistent 256x256 kernel it replaces (variant 6: LDS-transposed
+    epilogue): several tiles per workgroup, ragged last tiles in both directions, strided outputs.  The two kernels sum the 64 products of a
+    K-tile in different orders, so bf16 results may differ in the last bit here and there; fp32 results to contraction rounding."""
+    from acai_omr_amd import _lib, ops
+    M, N = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    bf = torch.bfloat16
+    a = torch.randn(M, K, generator=g).to(dev).to(bf)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev).to(bf)
+    b = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    saved = torch.randn(M, N, generator=g).to(dev).to(bf)
+    wide = torch.zeros(M, N + 40, device=dev, dtype=bf)
+
+    def run(variant):
+        _lib.check(_lib.lib().acai_gemm_set_variant(variant), "acai_gemm_set_variant")
+        try:
+            out = {}
+            out["plain_bf16"] = ops.gemm_nt(a, w, b, out_dtype=bf, round_bf16=True)
+            out["plain_f32"] = ops.gemm_nt(a, w, b)
+            out["nobias_f32"] = ops.gemm_nt(a, w)
+            out["res_f32"] = ops.gemm_nt(a, w, b, residual=res, round_bf16=True)
+            out["gelu_res_f32"] = ops.gemm_nt(a, w, b, residual=res, gelu=True, round_bf16=True)
+            pre = torch.empty(M, N, dtype=bf, device=dev)
+            out["gelu_bf16"] = ops.gemm_nt(a, w, b, out_dtype=bf, gelu=True, round_bf16=True, pre_act=pre)
+            out["pre_bf16"] = pre
+            out["dgelu_bf16"] = ops.gemm_nt(a, w, out_dtype=bf, round_bf16=True, gelu_grad_of=saved)
+            out["scale_bf16"] = ops.gemm_nt(a, w, b, out_dtype=bf, round_bf16=True, col_scale=(N // 3 // 4 * 4, ops.QSCALE(64)))
+            view = wide[:, 8:8 + N]
+            ops.gemm_nt(a, w, b, out=view, round_bf16=True)
+            out["strided_bf16"] = view.clone()
+            torch.cuda.synchronize()
+            return out
+        finally:
+            _lib.lib().acai_gemm_set_variant(0)
+
+    new, old = run(7), run(6)
+    base = (a.float().cpu().double() @ w.float().cpu().double().t() + b.cpu().double())
+    assert (new["plain_f32"].cpu().double() - base).abs().max() < 1e-4 * K ** 0.5 + 1e-4
+    assert float(wide[:, :8].abs().max()) == 0.0 and float(wide[:, 8 + N:].abs().max()) == 0.0    # nothing written outside the view
+    for k in new:
+        x, y = new[k].float(), old[k].float()
+        d = (x - y).abs()
+        if k.endswith("bf16"):
+            assert bool((d <= 2.0 ** -7 * y.abs() + 1e-6).all()), (k, float(d.max()))
+            assert float((d > 0).float().mean()) < 0.01, (k, float((d > 0).float().mean()))
+        else:
+            # a bf16-rounded linear output inside an fp32 sum can flip by one bf16 ulp of the linear term
+            tol = 2.0 ** -7 * (y.abs() + 4.0) if ("res" in k) else 1e-5 * (y.abs() + 1.0) * K ** 0.5
+            assert bool((d <= tol).all()), (k, float(d.max()))
+            assert float((d > 1e-5 * (y.abs() + 1.0) * K ** 0.5).float().mean()) < 0.01, k
