@@ -543,6 +543,21 @@ __device__ __forceinline__ void glds16s(uint32_t lds_dst, const void *sbase, uin
                  : "memory");
 }
 
+// four pieces of one 32 KB unit (consecutive 1 KiB destinations 8 KiB apart: wave w's pieces of a [256][128 B] image) in one block: one M0
+// save / restore instead of four
+__device__ __forceinline__ void glds16s_x4(uint32_t lds_dst, const void *sbase, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3) {
+    uint32_t m0_save;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %6\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %6\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %6\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(m0_save)
+                 : "s"(lds_dst), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(sbase)
+                 : "memory", "scc");
+}
+
 // ---- 256x128 tile, 8 waves, THREE LDS stages (144 KB): two K-tiles in flight ------------------------------------------------------------
 // The two-stage kernels are latency-bound, not MFMA-bound (PMC: MFMA busy 36 %, a third of the wave cycles in s_waitcnt, L2 hit rate 64 %):
 // with one tile in flight per workgroup a CU has 64 KB outstanding, and 64 KB x 256 CUs / ~1.2 us of loaded L2/fabric latency is exactly the
@@ -1224,18 +1239,22 @@ __device__ __forceinline__ void pp_swap2(uint32_t &x, uint32_t &y) {
     x = r[0];
     y = r[1];
 }
-__device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 (&acc)[8][4], int m0, int n0, int lane) {
+// MODE (compile-time: one kernel instantiation per epilogue form - with every form in one body the kernel was > 100 KB of code, more than the
+// instruction cache, and a plain bf16 epilogue took ~10 us per tile walking around the other forms' blocks)
+enum { PP_OBF = 1, PP_GELU = 2, PP_AUX1 = 4, PP_AUX2 = 8, PP_RES = 16, PP_SCALE = 32 };
+template <int MODE>
+__device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 (&acc)[8][4], int m0, int n0, int lane, float bv) {
     const int lm = lane & 15, lq = lane >> 4;
-    const bool obf = g.out_dtype == ACAI_BF16;
-    const bool do_gelu = g.flags & ACAI_GEMM_GELU, do_round = g.flags & ACAI_GEMM_ROUND_BF16;
-    const bool pre_round = do_round && (do_gelu || g.aux_mode != 0 || g.residual != nullptr || !obf);
-    const int es = obf ? 2 : 4;
+    constexpr bool obf = MODE & PP_OBF, do_gelu = MODE & PP_GELU, has_res = MODE & PP_RES, has_scale = MODE & PP_SCALE;
+    constexpr int aux_mode = (MODE & PP_AUX1) ? 1 : ((MODE & PP_AUX2) ? 2 : 0);
+    const bool do_round = g.flags & ACAI_GEMM_ROUND_BF16;
+    const bool pre_round = do_round && (do_gelu || aux_mode != 0 || has_res || !obf);
+    constexpr int es = obf ? 2 : 4;
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)((size_t)g.M * g.ldc * es), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.residual ? g.residual : reinterpret_cast<const float *>(g.C)), 0,
-                                                                        g.residual ? (int)((size_t)g.M * g.ldr * 4) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(g.aux_mode ? g.aux : g.C, 0, g.aux_mode ? (int)((size_t)g.M * g.ldaux * es) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(has_res ? g.residual : reinterpret_cast<const float *>(g.C)), 0,
+                                                                        has_res ? (int)((size_t)g.M * g.ldr * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(aux_mode ? g.aux : g.C, 0, aux_mode ? (int)((size_t)g.M * g.ldaux * es) : 0, 0x00020000);
     constexpr uint32_t OOB = 0xFFFFFFF0u;
-    const bool has_scale = g.scale_cols > 0;
     // swapped (bf16) position of this lane inside a block pair: block 2p + (lq & 1), columns 8 (lq >> 1) .. + 7
     const int sw_col = n0 + (lq & 1) * 16 + (lq >> 1) * 8;
 #pragma unroll
@@ -1246,7 +1265,10 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
         for (int t = 0; t < 2; ++t) {
             const int nb = 2 * p + t, col = n0 + nb * 16 + 4 * lq;
             colok[nb] = col < g.N;
-            bias4[nb] = (g.bias && colok[nb]) ? *reinterpret_cast<const f32x4 *>(g.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            // lane L of `bv` holds bias[n0 + L] (zero beyond N / without a bias), loaded by the caller a K-step ahead: a vector-memory load HERE
+            // would be waited for behind the LDS-DMA just issued (vmcnt counts in order) - 3.6 us per tile on the decoder's in-projection
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias4[nb][e] = __shfl(bv, nb * 16 + 4 * lq + e);
         }
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb) {
@@ -1256,9 +1278,9 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
             const bool swok = rowok && (sw_col + p * 32) < g.N;
             const uint32_t off_sw_c = swok ? (uint32_t)(((size_t)row * g.ldc + sw_col + p * 32) * 2) : OOB;
             const uint32_t off_sw_x = swok ? (uint32_t)(((size_t)row * g.ldaux + sw_col + p * 32) * 2) : OOB;
-            float a0[2][4];
-            if (g.aux_mode == 2) {
-                if (obf) {
+            float a0[2][4] = {};
+            if constexpr (aux_mode == 2) {
+                if constexpr (obf) {
                     u32x4_t L = __builtin_amdgcn_raw_buffer_load_b128(rx, off_sw_x, 0, 0);
                     uint32_t x0 = L[0], x1 = L[1], y0 = L[2], y1 = L[3];
                     pp_swap2(x0, y0);
@@ -1282,7 +1304,7 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
             for (int t = 0; t < 2; ++t) {
                 const int nb = 2 * p + t;
                 v[t] = acc[mb][nb] + bias4[nb];
-                if (has_scale) {
+                if constexpr (has_scale) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[t][e] *= (n0 + nb * 16 + 4 * lq + e) < g.scale_cols ? g.col_scale : 1.0f;
                 }
@@ -1291,8 +1313,8 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
                     for (int e = 0; e < 4; ++e) v[t][e] = round_bf16(v[t][e]);
                 }
             }
-            if (g.aux_mode == 1) {   // keep the pre-activation
-                if (obf) {
+            if constexpr (aux_mode == 1) {   // keep the pre-activation
+                if constexpr (obf) {
                     uint32_t x0 = pack_bf16(v[0][0], v[0][1]), x1 = pack_bf16(v[0][2], v[0][3]), y0 = pack_bf16(v[1][0], v[1][1]), y1 = pack_bf16(v[1][2], v[1][3]);
                     pp_swap2(x0, y0);
                     pp_swap2(x1, y1);
@@ -1309,32 +1331,34 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int nb = 2 * p + t, col = n0 + nb * 16 + 4 * lq;
-                if (g.aux_mode == 2) {
+                if constexpr (aux_mode == 2) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[t][e] *= gelu_erf_grad(a0[t][e]);
                 }
-                if (do_gelu) {
+                if constexpr (do_gelu) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[t][e] = gelu_erf(v[t][e]);
                         if (do_round) v[t][e] = round_bf16(v[t][e]);
                     }
                 }
-                if (g.residual) {
+                if constexpr (has_res) {
                     const uint32_t o = (rowok && colok[nb]) ? (uint32_t)(((size_t)row * g.ldr + col) * 4) : OOB;
                     const u32x4_t L = __builtin_amdgcn_raw_buffer_load_b128(rr, o, 0, 0);
                     v[t] += __builtin_bit_cast(f32x4, L);
                 }
-                if (!obf) {
+                if constexpr (!obf) {
                     const uint32_t o = (rowok && colok[nb]) ? (uint32_t)(((size_t)row * g.ldc + col) * 4) : OOB;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[t]), rc, o, 0, 0);
                 }
             }
-            if (obf) {
+            if constexpr (obf) {
                 uint32_t x0 = pack_bf16(v[0][0], v[0][1]), x1 = pack_bf16(v[0][2], v[0][3]), y0 = pack_bf16(v[1][0], v[1][1]), y1 = pack_bf16(v[1][2], v[1][3]);
                 pp_swap2(x0, y0);
                 pp_swap2(x1, y1);
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{x0, x1, y0, y1}, rc, off_sw_c, 0, 0);
+                const int dbg = g.flags >> 8;
+                if (dbg & 128) asm volatile("" ::"v"(x0), "v"(x1), "v"(y0), "v"(y1));
+                else __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{x0, x1, y0, y1}, rc, (dbg & 64) ? (off_sw_c & 0xFFFF0u) : off_sw_c, 0, 0);
             }
         }
     }
@@ -1362,7 +1386,7 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
 //     G0: R(q,0) = seg 4q, M(q,0) = 4q+1, R(q,1) = 4q+2, M(q,1) = 4q+3;    G1: the same one segment later (4q+1 .. 4q+4)
 //     slots of K-step q are last read in seg 4q+3 (G1, reads waited with lgkmcnt(0) before b_{4q+3}) and refilled from seg 4q+4 on;
 //     every wave waits for ITS pieces of K-step q+1 (vmcnt) before b_{4q+3}; the first read of K-step q+1 is in seg 4q+4.
-template <typename T>
+template <typename T, int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_pp_kernel(GemmArgs g) {
     static_assert(sizeof(T) == 2, "bf16 row-major operands");
     constexpr int BK = ROWB / sizeof(T);
@@ -1384,6 +1408,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     typedef __attribute__((address_space(3))) void *lds_ptr;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr)lds;
 
+    // timing ablations (ACAI_GEMM_DEBUG, results are wrong): 1 no counted waits, 2 no LDS-DMA, 4 no epilogue, 8 no MFMAs, 16 no fragment reads,
+    // 32 start-up skew of the workgroups
+    const int dbg = g.flags >> 8;
     // ---- producer (as pers256): one cursor per operand, A runs one K-step ahead of W ----
     // Sources as a uniform base (SGPR pair: the tile's first row, advanced per K-step) + a 32-bit byte offset per lane: (row within the tile,
     // clamped to the operand's last row) x pitch + the swizzled 16-byte slot.  24-bit multiplies (the host checks pitch < 2^24 bytes).
@@ -1421,8 +1448,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
         if (a_done >= total) return;
         const uint32_t lb = lds_base + p_slot * UNIT;
         const T *base = tileA + (size_t)a_kt * BK;   // uniform
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16s(__builtin_amdgcn_readfirstlane(lb + (wave * 4 + i) * 1024), base, offA[i]);
+        if (!(dbg & 2)) glds16s_x4(__builtin_amdgcn_readfirstlane(lb + wave * 4096), base, offA[0], offA[1], offA[2], offA[3]);
         if (++a_kt == nkt) {
             a_kt = 0;
             if (++a_tile < n_my) set_a(a_tile);
@@ -1434,8 +1460,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
         if (w_done >= total) return;
         const uint32_t lb = lds_base + p_slot * UNIT;
         const T *base = tileW + (size_t)w_kt * BK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16s(__builtin_amdgcn_readfirstlane(lb + (wave * 4 + i) * 1024), base, offW[i]);
+        if (!(dbg & 2)) glds16s_x4(__builtin_amdgcn_readfirstlane(lb + wave * 4096), base, offW[0], offW[1], offW[2], offW[3]);
         if (++w_kt == nkt) {
             w_kt = 0;
             if (++w_tile < n_my) set_w(w_tile);
@@ -1495,8 +1520,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
             default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         }
     };
-    const int n_st = g.out_dtype == ACAI_BF16 ? (g.aux_mode == 1 ? 32 : 16) : 32;   // store instructions per wave and tile (host: vec_epi only)
+    constexpr int n_st = (MODE & PP_OBF) ? ((MODE & PP_AUX1) ? 32 : 16) : 32;   // store instructions per wave and tile (host: vec_epi only)
 
+    // The bias of the tile in flight, one column per lane (lane L: bias[bn0 + wn*64 + L]); the epilogue distributes it with ds_bpermute and
+    // issues no vector-memory load of its own.  A compiler-visible load anywhere in this loop is waited for with vmcnt(0) at its first use,
+    // i.e. behind whatever LDS-DMA is in flight then (vmcnt counts in order): 2.5-3.6 us per tile, measured at three placements.  So the load is
+    // an asm statement the wait-count pass does not see, issued in the tile's FIRST K-step in front of that step's LDS-DMA; the counted wait at
+    // the end of the same K-step retires it together with everything older than W(q+1), and its first use is at least one barrier later.  The
+    // register is tied in and out of the asm ("+v"): no copy of it can be scheduled between the issue and the wait.
+    uint32_t bvr = 0;
+    int c_tile = 0, c_kt = 0, slot_a = 0;
+    auto load_bias = [&]() {
+        int bm0, bn0;
+        tile_origin(c_tile, bm0, bn0);
+        const uint32_t off = (uint32_t)min(bn0 + wn * 64 + lane, g.N - 1) * 4;
+        asm volatile("global_load_dword %0, %1, %2" : "+v"(bvr) : "v"(off), "s"(g.bias) : "memory");
+    };
     set_a(0);
     set_w(0);
     issue_a();   // A(0)
@@ -1506,37 +1545,44 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     if (total > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PP_BAR();              // b_{-1}: K-step 0 has landed for everybody
+    if (dbg & 32) {
+        for (int i = 0; i < (int)(blockIdx.x / 8 % 8); ++i) __builtin_amdgcn_s_sleep(32);   // ~ (w/8 % 8) x 1 us
+    }
     if (grp == 1) PP_BAR();   // G1 runs one segment behind
-    int c_tile = 0, c_kt = 0, slot_a = 0;
     for (int q = 0; q <= total; ++q) {
         const bool live = q < total;    // the extra pass q == total only runs the last tile's epilogue (and keeps the barrier count)
         const int slot_w = slot_a == NSLOT - 1 ? 0 : slot_a + 1;
         const unsigned char *sa = lds + slot_a * UNIT, *sb = lds + slot_w * UNIT;
         // ---- R(q, 0) ----
+        float bv = __uint_as_float(bvr);    // the finished tile's bias (its load was retired K-steps ago), before the next tile's load reuses the register
+        if (!live) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv)::"memory");   // (a single-K-step last tile: no counted wait came after its load)
+        if (live && c_kt == 0 && g.bias) load_bias();
         issue_w();   // W(q+1) -> the slot A(q-1) left
         int allow = q + 2 < total ? 4 : 0;
         if (c_kt == 0 && q > 0) {
             int bm0, bn0;
             tile_origin(c_tile - 1, bm0, bn0);
-            gemm_pp_epilogue(g, acc, bm0 + wm * 128, bn0 + wn * 64, lane);
+            if (!(dbg & 4)) {
+                gemm_pp_epilogue<MODE>(g, acc, bm0 + wm * 128, bn0 + wn * 64, lane, g.bias ? bv : 0.f);
+                allow += n_st;
+            }
             zero_acc();
-            allow += n_st;
         }
-        issue_a();   // A(q+2) -> the slot W(q-1) left
-        if (live) reads(sa, sb, offk0);   // (after the epilogue: the fragment registers are not live across it)
+        if (live && !(dbg & 16)) reads(sa, sb, offk0);   // (after the epilogue: the fragment registers are not live across it)
         PP_LGKM0();
         PP_BAR();
         // ---- M(q, 0) ----
-        if (live) mfmas();
+        if (live && !(dbg & 8)) mfmas();
         PP_BAR();
         // ---- R(q, 1) ----
-        if (live) reads(sa, sb, offk1);
+        issue_a();   // A(q+2) -> the slot W(q-1) left (the K-step's eight LDS-DMA pieces are split over its two R segments)
+        if (live && !(dbg & 16)) reads(sa, sb, offk1);
         PP_LGKM0();
-        if (grp == 1 && q + 1 < total) wait_step(allow);
+        if (grp == 1 && q + 1 < total && !(dbg & 1)) wait_step(allow);
         PP_BAR();
         // ---- M(q, 1) ----
-        if (live) mfmas();
-        if (grp == 0 && q + 1 < total) wait_step(allow);
+        if (live && !(dbg & 8)) mfmas();
+        if (grp == 0 && q + 1 < total && !(dbg & 1)) wait_step(allow);
         PP_BAR();
         if (live && ++c_kt == nkt) {
             c_kt = 0;
@@ -1655,6 +1701,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     gemm_accum_epilogue(g, acc, bm0, bn0, wm, wn, lr, lh);
 }
 
+// epilogue form of a launch as gemm_nt_pp_kernel's MODE, and the forms it is instantiated for (the others keep variant 6)
+static inline int pp_mode(const GemmArgs &g) {
+    return (g.out_dtype == ACAI_BF16 ? PP_OBF : 0) | ((g.flags & ACAI_GEMM_GELU) ? PP_GELU : 0) | (g.aux_mode == 1 ? PP_AUX1 : 0) | (g.aux_mode == 2 ? PP_AUX2 : 0) |
+           (g.residual ? PP_RES : 0) | (g.scale_cols > 0 ? PP_SCALE : 0);
+}
+static inline bool pp_mode_ok(int m) {
+    return m == PP_OBF || m == (PP_OBF | PP_SCALE) || m == (PP_OBF | PP_GELU | PP_AUX1) || m == (PP_OBF | PP_AUX2) || m == 0 || m == PP_RES;
+}
+
 int g_gemm_variant = getenv("ACAI_GEMM_VARIANT") ? atoi(getenv("ACAI_GEMM_VARIANT")) : 0;
 
 template <typename T, int EPI, bool TA = false, bool TB = false>
@@ -1748,14 +1803,26 @@ int launch(const GemmArgs &g, hipStream_t st) {
             const size_t lim = 0xFFFFFF00ull, esz = g.out_dtype == ACAI_BF16 ? 2 : 4;
             const bool fits = (size_t)g.M * g.ldc * esz < lim && (!g.residual || (size_t)g.M * g.ldr * 4 < lim) && (!g.aux_mode || (size_t)g.M * g.ldaux * esz < lim);
             const bool src32 = (size_t)g.lda * 2 < (1u << 24) && (size_t)g.ldw * 2 < (1u << 24);   // 24-bit multiplies in the lane offsets of the LDS-DMA sources
-            if (!(sizeof(T) == 2 && EPI == 0) || !fits || !src32 || !h.vec_epi) v = 6;
+            if (!(sizeof(T) == 2 && EPI == 0) || !fits || !src32 || !h.vec_epi || !pp_mode_ok(pp_mode(h))) v = 6;
         }
         if ((v == 5 || v == 6 || v == 7) && nwg256 < 8) v = 1;
         if (v == 4 && nwg4 < 8) v = 1;
         switch (v) {
             case 7:
                 if constexpr (sizeof(T) == 2 && EPI == 0) {
-                    hipLaunchKernelGGL((gemm_nt_pp_kernel<T>), dim3(nwg256 < n_cu ? nwg256 : n_cu), dim3(512), 0, st, h);
+                    if (const char *d = getenv("ACAI_GEMM_DEBUG")) h.flags |= atoi(d) << 8;
+                    const dim3 grid(nwg256 < n_cu ? nwg256 : n_cu), block(512);
+                    switch (pp_mode(h)) {
+#define PP_CASE(M) case (M): hipLaunchKernelGGL((gemm_nt_pp_kernel<T, (M)>), grid, block, 0, st, h); break
+                        PP_CASE(PP_OBF);
+                        PP_CASE(PP_OBF | PP_SCALE);
+                        PP_CASE(PP_OBF | PP_GELU | PP_AUX1);
+                        PP_CASE(PP_OBF | PP_AUX2);
+                        PP_CASE(0);
+                        PP_CASE(PP_RES);
+#undef PP_CASE
+                        default: break;   // unreachable: pp_mode_ok() sent every other form to variant 6
+                    }
                     break;
                 }
             case 6:
