@@ -1270,8 +1270,39 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
 #pragma unroll
             for (int e = 0; e < 4; ++e) bias4[nb][e] = __shfl(bv, nb * 16 + 4 * lq + e);
         }
+        // Every load of this block pair first (the saved pre-activation of aux_mode 2, the fp32 residual: 8 or 16 x 16 bytes per lane), then
+        // the arithmetic and the stores: load -> use -> store per 16 rows made a chain of 16 dependent memory round trips per epilogue
+        // (~30 us per tile on the decoder's gelu' GEMM).
+        // (four 16-row blocks at a time: all eight spilled the residual form)
 #pragma unroll
-        for (int mb = 0; mb < 8; ++mb) {
+        for (int mh = 0; mh < 2; ++mh) {
+        u32x4_t prex[8][2], prer[8][2];
+#pragma unroll
+        for (int mb = 4 * mh; mb < 4 * mh + 4; ++mb) {
+            const int row = m0 + mb * 16 + lm;
+            const bool rowok = row < g.M;
+            if constexpr (aux_mode == 2) {
+                if constexpr (obf) {
+                    const bool swok = rowok && (sw_col + p * 32) < g.N;
+                    prex[mb][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, swok ? (uint32_t)(((size_t)row * g.ldaux + sw_col + p * 32) * 2) : OOB, 0, 0);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int nb = 2 * p + t, col = n0 + nb * 16 + 4 * lq;
+                        prex[mb][t] = __builtin_amdgcn_raw_buffer_load_b128(rx, (rowok && colok[nb]) ? (uint32_t)(((size_t)row * g.ldaux + col) * 4) : OOB, 0, 0);
+                    }
+                }
+            }
+            if constexpr (has_res) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int nb = 2 * p + t, col = n0 + nb * 16 + 4 * lq;
+                    prer[mb][t] = __builtin_amdgcn_raw_buffer_load_b128(rr, (rowok && colok[nb]) ? (uint32_t)(((size_t)row * g.ldr + col) * 4) : OOB, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int mb = 4 * mh; mb < 4 * mh + 4; ++mb) {
             const int row = m0 + mb * 16 + lm;
             const bool rowok = row < g.M;
             f32x4 v[2];
@@ -1281,7 +1312,7 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
             float a0[2][4] = {};
             if constexpr (aux_mode == 2) {
                 if constexpr (obf) {
-                    u32x4_t L = __builtin_amdgcn_raw_buffer_load_b128(rx, off_sw_x, 0, 0);
+                    const u32x4_t L = prex[mb][0];
                     uint32_t x0 = L[0], x1 = L[1], y0 = L[2], y1 = L[3];
                     pp_swap2(x0, y0);
                     pp_swap2(x1, y1);
@@ -1292,9 +1323,7 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
                 } else {
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        const int nb = 2 * p + t, col = n0 + nb * 16 + 4 * lq;
-                        const uint32_t o = (rowok && colok[nb]) ? (uint32_t)(((size_t)row * g.ldaux + col) * 4) : OOB;
-                        const u32x4_t L = __builtin_amdgcn_raw_buffer_load_b128(rx, o, 0, 0);
+                        const u32x4_t L = prex[mb][t];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) a0[t][e] = __uint_as_float(L[e]);
                     }
@@ -1342,11 +1371,7 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
                         if (do_round) v[t][e] = round_bf16(v[t][e]);
                     }
                 }
-                if constexpr (has_res) {
-                    const uint32_t o = (rowok && colok[nb]) ? (uint32_t)(((size_t)row * g.ldr + col) * 4) : OOB;
-                    const u32x4_t L = __builtin_amdgcn_raw_buffer_load_b128(rr, o, 0, 0);
-                    v[t] += __builtin_bit_cast(f32x4, L);
-                }
+                if constexpr (has_res) v[t] += __builtin_bit_cast(f32x4, prer[mb][t]);
                 if constexpr (!obf) {
                     const uint32_t o = (rowok && colok[nb]) ? (uint32_t)(((size_t)row * g.ldc + col) * 4) : OOB;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[t]), rc, o, 0, 0);
@@ -1360,6 +1385,7 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
                 if (dbg & 128) asm volatile("" ::"v"(x0), "v"(x1), "v"(y0), "v"(y1));
                 else __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{x0, x1, y0, y1}, rc, (dbg & 64) ? (off_sw_c & 0xFFFF0u) : off_sw_c, 0, 0);
             }
+        }
         }
     }
 }
@@ -1798,6 +1824,20 @@ int launch(const GemmArgs &g, hipStream_t st) {
             if (g_gemm_variant == 0 && !no_p256 && (v == 4 || v == 3) && ktiles < 64 && nwg256 >= n_cu && nwg256 * 100 >= rounds256 * n_cu * 95 &&
                 !(g.N <= 512 && ktiles <= 8))
                 v = 6;
+        }
+        // Round 3: wherever one of the large-tile kernels was chosen, the ping-pong ring (7) replaces it when the launch has one of its epilogue
+        // forms (tools/bench_pp.py, MAE step shapes, same box: every shape faster - 0.82-1.02 PF on the plain / residual forms against 0.32-0.84).
+        if constexpr (sizeof(T) == 2 && EPI == 0) {
+            static const bool no_pp = getenv("ACAI_GEMM_NO_PP") != nullptr;   // A/B aid
+            if (g_gemm_variant == 0 && !no_pp && v >= 3 && v <= 6) v = 7;
+            // ... and it replaces the 128x128 kernel on mid-size problems when it needs fewer rounds of the chip: 128x128 tiles run two workgroups
+            // per CU, a 256x256 tile (four of them) takes ~1.54 of their tile times on the ring.  The teacher-forced decoder stream (M = 16 x 513
+            // = 8208 rows: 520 tiles of 128x128 at N = 1024, two rounds for 1.02 rounds of work) is the case: 37.9 -> 31.8 us at K = 1024,
+            // 111.8 -> 96.0 us at K = 4096, N = 3072 76.7 -> 60.7 us (tools/bench_gemm_tf.py); M = 8192 (exactly one round) keeps the 128x128 kernel.
+            if (g_gemm_variant == 0 && !no_pp && v == 1 && nwg256 >= 8) {
+                const int rounds1 = cdiv(nwg, 2 * n_cu), rounds7 = cdiv(nwg256, n_cu);
+                if (rounds7 * 154 < rounds1 * 100) v = 7;
+            }
         }
         if (v == 7) {   // the register epilogue addresses C / residual / aux through 32-bit buffer offsets
             const size_t lim = 0xFFFFFF00ull, esz = g.out_dtype == ACAI_BF16 ? 2 : 4;
