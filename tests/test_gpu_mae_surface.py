@@ -205,8 +205,14 @@ def test_uncached_rollout_policy(dev):
         mem = g.transition_head(lat)
         r, lp, m = g.uncached_forward_rollout_policy(mem, mask, max_actions=cfg["gen_len"], top_k=1, temperature=1.2)
     assert r.shape == (len(fx["imgs"]), cfg["gen_len"]) and lp.shape == r.shape and m.dtype == torch.bool
-    ref = fx["ref_fp32"]["seqs"]
-    T = ref.shape[1]
-    assert torch.equal(r.cpu()[:, :T], ref)
+    # top_k = 1 makes every draw the argmax of the UNCACHED forward on the prefix (positions 0..t-1: not the cached loop's off-by-one)
+    with torch.no_grad():
+        seqs = torch.full_like(r, g.decoder.pad_idx)
+        seqs[:, 0] = g.decoder.bos_idx
+        for t in range(1, cfg["gen_len"]):
+            seqs[:, t] = g.decoder.generate(seqs[:, :t], mem, latent_attention_mask=mask)[:, -1, :].float().argmax(-1)
+            if bool((seqs == g.decoder.eos_idx).any(-1).all()):
+                break
+    assert torch.equal(r.masked_fill(~m, g.decoder.pad_idx), seqs.masked_fill(~g.create_inference_mask(seqs), g.decoder.pad_idx))
     assert float(lp.abs().max()) == 0.0          # one kept logit: log_softmax over the masked vocabulary is 0 for the survivor
     assert torch.equal(r[~m].cpu(), torch.full_like(r[~m].cpu(), g.decoder.pad_idx))
