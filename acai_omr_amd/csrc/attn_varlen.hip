@@ -16,6 +16,16 @@
 // the MFMAs of tile t (issue-early / write-late) into the other of two LDS stages: one barrier per tile.
 #include "common.h"
 
+#ifndef ACAI_ATTN_QK_FIRST
+#define ACAI_ATTN_QK_FIRST 0
+#endif
+#ifndef ACAI_FWD_WAVES
+#define ACAI_FWD_WAVES 2
+#endif
+#ifndef ACAI_ATTN_PSUM4
+#define ACAI_ATTN_PSUM4 1
+#endif
+
 namespace {
 
 constexpr int KT = 64;   // keys per tile
@@ -34,7 +44,7 @@ struct AttnArgs {
 };
 
 template <typename T, int DHP, bool FAST, bool DROP, bool PRE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WAVES))) void attn_fwd_kernel(AttnArgs a) {
     constexpr int ES = sizeof(T);
     constexpr int EPC = 16 / ES;                 // elements per 16-byte chunk
     typedef TileLayout<ES, DHP> TL;              // natural [key][d] image of the K and V tiles (swizzled bf16 / padded fp32)
@@ -274,15 +284,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         if (kt + 1 < nkt) load_tile(kt + 1);
         f32x16 sacc[2] = {minit, minit};
         qk(sacc, ldsK);
-        float psum = 0.f;
+#if ACAI_ATTN_QK_FIRST
+        __builtin_amdgcn_sched_barrier(0);   // all four S^T MFMAs first: the second key block's run under the first block's exponentials
+#endif
+        // four independent partial sums: one running sum made a chain of 32 dependent v_add_f32 per tile (a dependent add issues every
+        // ~6.6 cycles instead of 4: +80 cycles per tile on a loop whose floor is ~520)
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float p = PRE ? fast_exp2(sacc[kb][e]) : fast_exp2(fmaf(sacc[kb][e], c, -m_run));
                 sacc[kb][e] = p;
-                psum += p;
+                ps[ACAI_ATTN_PSUM4 ? (e & 3) : 0] += p;
             }
+        const float psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
         bad |= !(psum < 1.2e24f);   // 2^80; also true for inf and NaN
         l_run += psum;
         pv(sacc, ldsV, kt);

@@ -1727,6 +1727,182 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     gemm_accum_epilogue(g, acc, bm0, bn0, wm, wn, lr, lh);
 }
 
+// ---- dW = dY^T X with ping-pong wave groups on the ring of half-stages (round 3) ---------------------------------------------------------
+// gemm_tn_ring_kernel (256 x 128 tile, three 48 KB stages, both waves of a SIMD in lock-step behind one barrier per K-step) ran the MAE's
+// weight gradients at 0.71-0.89 PF.  This is gemm_nt_pp_kernel's structure on the token-major operands: 256 (dY columns) x 256 (X columns)
+// tile, 8 waves as 2 x 4 (128 x 64 each, 16x16x32 MFMAs: 128 accumulator registers), K-step = 64 tokens, a unit = one operand's
+// [64 tokens][256 columns] image (32 KB, as two [64][128-column] images of 256-byte rows), five unit slots, the dY unit two K-steps ahead and
+// the X unit one, LDS-DMA from inline asm behind counted waits, and the two wave groups one segment apart (R: fragment reads + this
+// segment's four LDS-DMA pieces, M: 32 MFMAs; two of each per K-step).  Fragments - eight consecutive tokens of one column - come from
+// ds_read_b64_tr_b16 out of the natural image, whose 16-byte chunk c of token row r sits in slot c ^ (((r & 3) << 2) | ((r >> 2) & 3)): the
+// four token rows of a transposing read land in four different 64-byte blocks and the two 16-lane groups of a half-wave (token rows 8 apart)
+// in different 32-byte halves (cdna_hip_programming.md T10, image (b)).  One (tile, K-slice) per workgroup, split-K over the tokens so that
+// about one workgroup per CU exists, fp32 atomics straight from the accumulators: the un-swapped 16x16 layout gives a lane one column and
+// four consecutive rows, so a wave instruction adds four 64-byte row segments.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void gemm_tn_pp_kernel(GemmArgs g) {
+    typedef bf16_t T;
+    constexpr int BKT = 64, BT = 256, UNIT = BKT * BT * 2, NSLOT = 5, IMG = BKT * 256;   // 32 KB per unit, 16 KB per 128-column image
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NSLOT * UNIT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3, grp = wm;
+    const int nbn = (g.N + BT - 1) / BT, nbm = (g.M + BT - 1) / BT, nwg = nbn * nbm;
+    int pid = blockIdx.x, kslice = 0;
+    if (g.ksplit > 1) {
+        kslice = pid / nwg;
+        pid -= kslice * nwg;
+    }
+    const int bm0 = (pid / nbn) * BT, bn0 = (pid % nbn) * BT;
+    int nkt = g.K / BKT, kt_begin = 0;
+    if (g.ksplit > 1) {
+        const int per = (nkt + g.ksplit - 1) / g.ksplit;
+        kt_begin = kslice * per;
+        nkt = min(nkt, kt_begin + per);
+        if (kt_begin >= nkt) return;  // uniform per workgroup, before any barrier
+    }
+    const int total = nkt - kt_begin;
+    const T *A = reinterpret_cast<const T *>(g.A) + (size_t)kt_begin * BKT * g.lda;
+    const T *W = reinterpret_cast<const T *>(g.W) + (size_t)kt_begin * BKT * g.ldw;
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr)lds;
+
+    // ---- producer: piece j (0..31) of a unit = image j / 16, token rows 4 (j % 16) .. + 3; wave w issues pieces 4w .. 4w+3 (4 KB of LDS in a row).
+    // Lane l of a piece: token row 4 (j % 16) + l / 16, LDS slot l % 16 <- logical chunk (l % 16) ^ swz(row).  Columns beyond the operand
+    // are clamped to its last whole chunk (their outputs are never stored).
+    uint32_t offA[4], offW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = wave * 4 + i, row = 4 * (j & 15) + (lane >> 4);
+        const int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        const int col = 128 * (j >> 4) + 8 * ch;
+        offA[i] = (uint32_t)row * (uint32_t)(g.lda * 2) + (uint32_t)min(bm0 + col, g.M - 8) * 2;
+        offW[i] = (uint32_t)row * (uint32_t)(g.ldw * 2) + (uint32_t)min(bn0 + col, g.N - 8) * 2;
+    }
+    int a_done = 0, w_done = 0, p_slot = 0;
+    auto next_slot = [&]() { p_slot = p_slot == NSLOT - 1 ? 0 : p_slot + 1; };
+    auto issue_a = [&]() {
+        if (a_done >= total) return;
+        glds16s_x4(__builtin_amdgcn_readfirstlane(lds_base + p_slot * UNIT + wave * 4096), A + (size_t)a_done * BKT * g.lda, offA[0], offA[1], offA[2], offA[3]);
+        ++a_done;
+        next_slot();
+    };
+    auto issue_w = [&]() {
+        if (w_done >= total) return;
+        glds16s_x4(__builtin_amdgcn_readfirstlane(lds_base + p_slot * UNIT + wave * 4096), W + (size_t)w_done * BKT * g.ldw, offW[0], offW[1], offW[2], offW[3]);
+        ++w_done;
+        next_slot();
+    };
+
+    // ---- consumer: D[m][n] += sum_tokens dY[token][m] X[token][n]; lane (col = lane & 15, lq = lane >> 4) of accumulator [mb][nb] holds
+    // C[mb*16 + 4*lq + e][nb*16 + col], e = 0..3 ----
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // transposing fragment read of the 16-column block at image column c0, contraction slice kh (32 tokens): lane 4q'+p' of a 16-lane group
+    // addresses token row t0 + q', columns c0 + 4p' .. + 3, t0 = 32 kh + 8 (lane >> 4) (+ 4 for the second read); lane i receives column i.
+    // Everything lane-dependent is folded into two byte offsets per kh (first / second read); the block's column enters as XOR (c0 / 8) << 4.
+    typedef __attribute__((ext_vector_type(4))) short s4;
+    typedef __attribute__((address_space(3))) s4 *lds_s4;
+    const int l16 = lane & 15, qp = l16 >> 2, pp = l16 & 3, lq = lane >> 4;
+    int fro[2][2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int h4 = 0; h4 < 2; ++h4) {
+            const int row = 32 * kh + 8 * lq + 4 * h4 + qp;
+            fro[kh][h4] = row * 256 + ((((pp >> 1)) ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4) + 8 * (pp & 1);
+        }
+    uint4 fa[8], fw[4];
+    auto frag = [&](const unsigned char *img, int c0, int kh) -> uint4 {
+        union { s4 v[2]; uint4 u; } r;
+        r.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(img + (fro[kh][0] ^ ((c0 >> 3) << 4))));
+        r.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(img + (fro[kh][1] ^ ((c0 >> 3) << 4))));
+        return r.u;
+    };
+    auto reads = [&](const unsigned char *sa, const unsigned char *sb, int kh) {
+        // this wave's 128 dY columns are image wm of the dY unit; its 64 X columns are columns (wn & 1) * 64 .. of image wn >> 1 of the X unit
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fw[j] = frag(sb + (wn >> 1) * IMG, (wn & 1) * 64 + j * 16, kh);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = frag(sa + wm * IMG, i * 16, kh);
+    };
+    auto mfmas = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fw[j]), acc[i][j], 0, 0, 0);
+    };
+#define PP_BAR()                                      \
+    do {                                              \
+        __builtin_amdgcn_sched_barrier(0);            \
+        asm volatile("s_barrier" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);            \
+    } while (0)
+#define PP_LGKM0()                                               \
+    do {                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    } while (0)
+    issue_a();   // A(0)
+    issue_w();   // W(0)
+    issue_a();   // A(1)
+    if (total > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BAR();
+    if (grp == 1) PP_BAR();   // G1 runs one segment behind
+    int slot_a = 0;
+    for (int q = 0; q < total; ++q) {
+        const int slot_w = slot_a == NSLOT - 1 ? 0 : slot_a + 1;
+        const unsigned char *sa = lds + slot_a * UNIT, *sb = lds + slot_w * UNIT;
+        // ---- R(q, 0) ----
+        issue_w();   // X(q+1) -> the slot dY(q-1) left
+        reads(sa, sb, 0);
+        PP_LGKM0();
+        PP_BAR();
+        // ---- M(q, 0) ----
+        mfmas();
+        PP_BAR();
+        // ---- R(q, 1) ----
+        issue_a();   // dY(q+2) -> the slot X(q-1) left
+        reads(sa, sb, 1);
+        PP_LGKM0();
+        if (grp == 1 && q + 1 < total) {
+            if (q + 2 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PP_BAR();
+        // ---- M(q, 1) ----
+        mfmas();
+        if (grp == 0 && q + 1 < total) {
+            if (q + 2 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PP_BAR();
+        slot_a = slot_a + 2 >= NSLOT ? slot_a + 2 - NSLOT : slot_a + 2;
+    }
+    if (grp == 0) PP_BAR();
+#undef PP_BAR
+#undef PP_LGKM0
+    // ---- split-K accumulation: four 64-byte row segments per wave instruction ----
+    const int m0 = bm0 + wm * 128 + 4 * lq, n0 = bn0 + wn * 64 + (lane & 15);
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const int col = n0 + nb * 16;
+            if (col < g.N) {
+                float *base = reinterpret_cast<float *>(g.C) + (size_t)(m0 + mb * 16) * g.ldc + col;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (m0 + mb * 16 + e < g.M) atomicAdd(base + (size_t)e * g.ldc, acc[mb][nb][e]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // epilogue form of a launch as gemm_nt_pp_kernel's MODE, and the forms it is instantiated for (the others keep variant 6)
 static inline int pp_mode(const GemmArgs &g) {
     return (g.out_dtype == ACAI_BF16 ? PP_OBF : 0) | ((g.flags & ACAI_GEMM_GELU) ? PP_GELU : 0) | (g.aux_mode == 1 ? PP_AUX1 : 0) | (g.aux_mode == 2 ? PP_AUX2 : 0) |
@@ -1773,7 +1949,19 @@ int launch(const GemmArgs &g, hipStream_t st) {
             int ks_r = 256 / tiles_r;            // one resident workgroup per CU: never more workgroups than CUs (a second, nearly empty round doubles the time)
             if (ks_r < 1) ks_r = 1;
             if (ks_r > nkt_r / 8) ks_r = nkt_r / 8;
-            if (!no_ring && ks_r >= 1 && nkt_r >= 16) {
+            // round 3: the ping-pong form (256 x 256 tiles) where the operands' lane offsets fit 32 bits
+            static const int tn_pp = getenv("ACAI_GEMM_TN_PP") ? atoi(getenv("ACAI_GEMM_TN_PP")) : 1;   // A/B aid
+            const int tiles_p = cdiv(g.M, 256) * cdiv(g.N, 256);
+            int ks_p = 256 / tiles_p;
+            if (ks_p < 1) ks_p = 1;
+            if (ks_p > nkt_r / 8) ks_p = nkt_r / 8;
+            const bool pp_fits = (size_t)64 * g.lda * 2 + (size_t)g.M * 2 < 0xFFFFFF00ull && (size_t)64 * g.ldw * 2 + (size_t)g.N * 2 < 0xFFFFFF00ull;
+            // (short K-slices keep the 256 x 128 ring: with fewer than ~24 K-steps per workgroup the atomics of the larger tile's extra
+            // splits cost more than the main loop gains - encoder dWo, 768 x 768 from 32768 tokens: 82 us on the ring, 89 us here)
+            if (tn_pp && !no_ring && ks_p >= 1 && nkt_r >= 16 && pp_fits && nkt_r / ks_p >= 24) {
+                m.ksplit = ks_p;
+                hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3(tiles_p * ks_p), dim3(512), 0, st, m);
+            } else if (!no_ring && ks_r >= 1 && nkt_r >= 16) {
                 m.ksplit = ks_r;
                 hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3(tiles_r * ks_r), dim3(512), 0, st, m);
             } else

@@ -398,3 +398,22 @@ def test_gemm_nt_pingpong_epilogues(dev, K, shape):
             tol = 2.0 ** -7 * (y.abs() + 4.0) if ("res" in k) else 1e-5 * (y.abs() + 1.0) * K ** 0.5
             assert bool((d <= tol).all()), (k, float(d.max()))
             assert float((d > 1e-5 * (y.abs() + 1.0) * K ** 0.5).float().mean()) < 0.01, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3072, 512, 16384), (520, 264, 8192 + 40), (768, 2304, 4096), (512, 512, 32768)])
+def test_gemm_weight_gradient_pingpong(dev, shape):
+    """dW = dY^T X on the ping-pong TN kernel (gemm_tn_pp_kernel: 256 x 256 tiles, transposing fragment reads out of the swizzled natural
+    image, split-K atomics from the 16x16 accumulators), long token counts incl. a ragged last 64-token tile, ragged output edges."""
+    from acai_omr_amd import ops
+    M, N, K = shape     # dW is [M, N], K tokens
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = torch.randn(K, M, generator=g).to(torch.bfloat16)
+    x = (torch.randn(K, N, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    ref = dy.float().double().t() @ x.float().double()
+    out = ops.gemm(dy.to(dev), x.to(dev), trans_a=True, trans_w=True, out_dtype=torch.float32)
+    err = (out.cpu().double() - ref).abs().max()
+    assert err < 2e-3 * float(ref.abs().max()) + 1e-4, float(err)
+    # accumulation into an existing gradient (the arena hands out zeroed views; a second product adds on top)
+    out2 = ops.gemm(dy.to(dev), x.to(dev), trans_a=True, trans_w=True, out=out)
+    assert (out2.cpu().double() - 2 * ref).abs().max() < 4e-3 * float(ref.abs().max()) + 2e-4

@@ -42,7 +42,20 @@ def case(name, M, N, K, resid=False, gelu=False, dgelu=False, scale=False):
     print(line, flush=True)
 
 
+def dw(name, M, N, K):   # dW[N, K] = dY[M, N]^T X[M, K]
+    dy = torch.randn(M, N, device=dev).to(bf); x = torch.randn(M, K, device=dev).to(bf)
+    out = torch.zeros(N, K, device=dev)
+    fn = lambda: ops.gemm(dy, x, trans_a=True, trans_w=True, out=out)
+    fn(); torch.cuda.synchronize()
+    ts = sorted(timed(fn, 6) for _ in range(5))
+    print(f"{name:26s} {M:7d} {N:5d} {K:5d}   {ts[2]*1e6:8.1f} us {2*M*N*K/ts[2]/1e12:6.0f} TF", flush=True)
+
+
 Me, Md = 32768, 131072
+if "dw" in os.environ.get("ACAI_BENCH_PP", ""):
+    for tag, M, d in (("enc", Me, 768), ("dec", Md, 512)):
+        dw(f"{tag} dWi", M, 3 * d, d); dw(f"{tag} dWo", M, d, d); dw(f"{tag} dW1", M, 3072, d); dw(f"{tag} dW2", M, d, 3072)
+    sys.exit(0)
 for tag, M, d in (("enc", Me, 768), ("dec", Md, 512)):
     case(f"{tag} qkv fwd (scale)", M, 3 * d, d, scale=True)
     case(f"{tag} out fwd (+res)", M, d, d, resid=True)
