@@ -56,6 +56,8 @@ _SIGNATURES = {
                                       c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "acai_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "acai_resize_bicubic_aa": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "acai_resize_to_patches": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                       c_int, c_void_p]),
     "acai_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "acai_attn_varlen_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_uint32, c_int, c_void_p]),

@@ -111,18 +111,34 @@ class Encoder(nn.Module):
         return _autocast_prec()
 
     def embed_packed(self, x):
-        """Packed batchify: returns x32 (M,E), xb (bf16 copy or None), lens, dims."""
+        """Packed batchify: returns x32 (M,E), xb (bf16 copy or None), lens, dims.  x: images, or a `utils.PackedPatches` (patch rows written by
+        the resize kernel: no Unfold / cast here)."""
         dev = self._device()
-        imgs = _as_image_list(x, dev)
-        dims = [self._grid(t) for t in imgs]
-        lens = [h * w for h, w in dims]
         prec = self._prec()
         bf = prec == "bf16"
         P = self.patch_size
-        patches = torch.empty(sum(lens), NUM_CHANNELS * P * P, dtype=torch.bfloat16 if bf else torch.float32, device=dev)
-        r0 = 0
-        for t in imgs:
-            r0 += ops.patchify(t, P, patches, r0)
+        from ..utils import PackedPatches
+        if isinstance(x, PackedPatches):
+            if x.patch_size != P or x.patches.shape[1] != NUM_CHANNELS * P * P:
+                raise ValueError(f"patch rows of size {x.patch_size} for an encoder with patch size {P}")
+            dims = list(x.dims)
+            for h_p, w_p in dims:
+                if not self._allow_pe_interpolation and (h_p > self.pe_max_height or w_p > self.pe_max_width):
+                    raise ValueError(f"{h_p} x {w_p} image is too large for max positional embedding grid of shape {self.pe_max_height} x {self.pe_max_width}")
+            lens = [h * w for h, w in dims]
+            patches = x.patches.to(device=dev)
+            want = torch.bfloat16 if bf else torch.float32
+            if patches.dtype != want:
+                patches = ops.cast_bf16(patches.float().contiguous()) if bf else patches.float()
+            patches = patches.contiguous()
+        else:
+            imgs = _as_image_list(x, dev)
+            dims = [self._grid(t) for t in imgs]
+            lens = [h * w for h, w in dims]
+            patches = torch.empty(sum(lens), NUM_CHANNELS * P * P, dtype=torch.bfloat16 if bf else torch.float32, device=dev)
+            r0 = 0
+            for t in imgs:
+                r0 += ops.patchify(t, P, patches, r0)
         pe = self._pe_packed(dims)
         wc = _wc(self)
         if not isinstance(self.projection, nn.Linear):     # a swapped-in module (the reference's tests use nn.Identity, tests/test_mae.py:12)
@@ -733,10 +749,19 @@ class ScheduledSamplingViTOMR(TeacherForcedViTOMR):
     def sample_and_mix_seqs(self, teacher_forcing_prob, tf_input_seqs, tf_pred_logits, sample_tau, use_hard_sampling, device):
         """Mix gold embeddings with expected embeddings of a Gumbel-softmax sample of the first pass (M:801-817).
         Tiny (B,T,227)x(227,E) work; stays in PyTorch-ROCm as SURVEY section 2.2 allows."""
+        from ..train import autograd_path as AP
         sample_mask = torch.rand(tf_input_seqs.shape, device=device) < (1 - teacher_forcing_prob)
-        gold = self.decoder.vocab_embedding(tf_input_seqs.to(device))
+        dec = self.decoder
+        W = dec.vocab_embedding.weight
+        B, T = tf_input_seqs.shape
+        # nn.Embedding (M:805) as a row gather of the HIP path; the <pad> row is read through a detached copy (padding_idx: it gets no gradient)
+        tok = tf_input_seqs.to(device).reshape(-1)
+        table = torch.cat([W, W[dec.pad_idx:dec.pad_idx + 1].detach()], 0)
+        idx = torch.where(tok == dec.pad_idx, torch.full_like(tok, W.shape[0]), tok).to(torch.int32).contiguous()
+        gold = AP.GatherRowsFn.apply(table, idx, None).view(B, T, -1)
         distr = F.gumbel_softmax(tf_pred_logits.float(), tau=sample_tau, hard=use_hard_sampling)
-        expected = distr @ self.decoder.vocab_embedding.weight
+        # (B, T, V) x (V, E) (M:809) on the path's own GEMM kernels, forward and both gradients (round 2 left it to ATen / hipBLASLt)
+        expected = AP.MatmulKNFn.apply(distr.reshape(B * T, -1), W, AP._prec(), _wc(dec)).view(B, T, -1).to(gold.dtype)
         expected = torch.cat([gold[:, 0:1, :], expected], dim=1)[:, :-1]
         return torch.where(sample_mask.unsqueeze(-1), expected, gold)
 

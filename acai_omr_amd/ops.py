@@ -194,6 +194,27 @@ def resize_bicubic_aa(img, size, clamp01=False):
     return out
 
 
+def resize_to_patches(img, size, P, out, row0, crop=None, clamp01=False):
+    """One (1,H,W) or (H,W) image on the GPU - fp32 in [0,1], or uint8 (scaled by 1/255 on load) - resized to `size` = (OH, OW) (bicubic,
+    antialiased, optional clamp) and written as the nn.Unfold(P, P) rows row0 .. of the packed patch stream `out` [rows, P*P] (fp32 or bf16):
+    the resize's height pass stores patch rows directly - no resized image tensor, no patchify launch, no bf16 cast.
+    crop = (top, left, h, w): the window of the resized image that is kept (DynamicResize's centre crop).  Returns the number of rows written."""
+    assert img.is_cuda and img.dtype in (torch.float32, torch.uint8) and img.is_contiguous()
+    if img.dim() == 3:
+        assert img.shape[0] == 1, "one channel (NUM_CHANNELS = 1)"
+        img = img[0]
+    H, W = img.shape
+    OH, OW = int(size[0]), int(size[1])
+    top, left, ch, cw = (0, 0, OH, OW) if crop is None else [int(v) for v in crop]
+    assert out.is_cuda and out.dim() == 2 and out.shape[1] == P * P and out.stride(1) == 1 and out.dtype in (torch.float32, torch.bfloat16)
+    n = (ch // P) * (cw // P)
+    assert row0 + n <= out.shape[0]
+    tmp = torch.empty(H, OW, dtype=torch.float32, device=img.device)
+    _lib.check(_lib.lib().acai_resize_to_patches(img.data_ptr(), 1 if img.dtype == torch.uint8 else 0, H, W, tmp.data_ptr(), out.data_ptr(), out.stride(0),
+                                                 int(row0), OH, OW, top, left, ch, cw, int(P), _dt(out), int(bool(clamp01)), _st(img)), "acai_resize_to_patches")
+    return n
+
+
 def gather_rows(table, idx, add=None, out=None):
     _chk(table, "table", torch.float32), _chk(idx, "idx", torch.int32)
     assert table.dim() == 2 and table.is_contiguous() and idx.dim() == 1 and idx.is_contiguous()

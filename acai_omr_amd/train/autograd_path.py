@@ -368,6 +368,29 @@ class GeluFn(Function):
         return ops.gelu_bwd(a, dh.contiguous().to(a.dtype))
 
 
+class MatmulKNFn(Function):
+    """y[M,N] = a[M,K] @ W[K,N] with W stored [K][N] (an embedding matrix used as a linear map: the expected embedding of scheduled sampling,
+    models.py:809).  Under autocast the operands are bf16 and so is y (what `@` does there); dA = dy W^T and dW = a^T dy on the same kernels."""
+
+    @staticmethod
+    def forward(ctx, a32, W, prec, wc):
+        bf = prec == "bf16"
+        ac = ops.cast_bf16(a32.contiguous()) if bf else a32.contiguous()
+        Wc = wc.w(W, prec)
+        ctx.save_for_backward(ac, Wc)
+        ctx.bf = bf
+        return ops.gemm(ac, Wc, trans_w=True, out_dtype=torch.bfloat16 if bf else torch.float32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ac, Wc = ctx.saved_tensors
+        dyc = dy.contiguous()
+        dyc = (ops.cast_bf16(dyc.float()) if dyc.dtype != torch.bfloat16 else dyc) if ctx.bf else dyc.float()
+        da = ops.gemm_nt(dyc, Wc, out_dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dW = ops.gemm(ac, dyc, trans_a=True, trans_w=True, out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        return da, dW, None, None
+
+
 class GatherRowsFn(Function):
     """out[i] = table[idx[i]] (+ add[i]); backward scatter-adds into the table."""
 
@@ -534,8 +557,16 @@ def encoder_forward_packed(enc, x):
     _check_dropout(enc)
     from ..models.models import _as_image_list
     prec, wc = _prec(), _wc(enc)
-    imgs = _as_image_list(x, enc._device())
-    patches, dims, lens = _patches(enc, imgs, prec)
+    from ..utils import PackedPatches
+    if isinstance(x, PackedPatches):     # patch rows written by the resize kernel (utils.DynamicResize.to_patches)
+        dims = list(x.dims)
+        lens = [h * w for h, w in dims]
+        patches = x.patches.to(enc._device())
+        with torch.no_grad():
+            patches = (patches if patches.dtype == torch.bfloat16 else ops.cast_bf16(patches.float().contiguous())) if prec == "bf16" else patches.float().contiguous()
+    else:
+        imgs = _as_image_list(x, enc._device())
+        patches, dims, lens = _patches(enc, imgs, prec)
     pe = _pe_rows(enc, enc.pos_embedding, dims)
     x32 = LinearFn.apply(patches, enc.projection.weight, enc.projection.bias, pe, prec, wc, True)
     cu = EG.cu_from_lens(lens, x32.device)

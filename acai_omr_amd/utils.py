@@ -80,6 +80,19 @@ def _device_image(img, device=None):
     return img.to(device=device if device is not None else torch.device("cuda", torch.cuda.current_device()), dtype=torch.float32).contiguous()
 
 
+class PackedPatches:
+    """A batch of images as the encoder's projection GEMM wants it: the nn.Unfold(P, P) rows of every image in ONE packed [sum N, P*P] tensor
+    (fp32, or bf16 for an autocast encoder) plus the patch grid (h_p, w_p) of each image.  `DynamicResize.to_patches` / `resize_batch_to_patches`
+    produce it straight from the resize kernel; `Encoder` / `OMREncoder` / `FineTuneOMREncoder` (`forward`, `forward_packed`) and the
+    `inference()` entry point accept it wherever they accept a list of image tensors."""
+
+    def __init__(self, patches, dims, patch_size):
+        self.patches, self.dims, self.patch_size = patches, [tuple(d) for d in dims], patch_size
+
+    def __len__(self):
+        return len(self.dims)
+
+
 class PatchDivisibleResize(torch.nn.Module):
     """`PatchDivisibleResize` (acai_omr/utils/utils.py:309-330): resize to the nearest lower patch-divisible size, bicubic + antialias, on the GPU.
     Takes a C x H x W tensor (CPU tensors are uploaded once); returns a GPU tensor."""
@@ -125,3 +138,44 @@ class DynamicResize(torch.nn.Module):
                 img = _center_crop(img, img.shape[-2], self.pe_max_width * self.patch_size)
             img = img.contiguous()
         return img
+
+
+    # ---- extension (second half): resize straight into the packed patch stream -----------------------------------------------
+    def _plan(self, h, w):
+        """Target size of `forward` for an h x w input and the centre-crop window (top, left, height, width) inside it."""
+        th, tw = dynamic_resize_target(h, w, self.patch_size, self.max_seq_len)
+        ch, cw = th, tw
+        if self.crop_imgs:
+            if th / self.patch_size > self.pe_max_height:
+                ch = self.pe_max_height * self.patch_size
+            if tw / self.patch_size > self.pe_max_width:
+                cw = self.pe_max_width * self.patch_size
+        top, left = int(round((th - ch) / 2.0)), int(round((tw - cw) / 2.0))
+        return (th, tw), (top, left, ch, cw)
+
+    def to_patches(self, imgs, dtype=torch.float32):
+        """`forward` + the encoder's Unfold in one step for a LIST of images: every image - a (1,H,W) / (H,W) float tensor in [0,1] or a uint8
+        tensor (what `v2.ToImage` yields; `ToDtype(float32, scale=True)`'s 1/255 is applied on load) - is resized, clamped, cropped and written
+        as patch rows of ONE packed tensor by the resize kernel's height pass.  Returns a `PackedPatches` the encoders accept directly;
+        patchify(forward(img)) gives the same rows bit for bit."""
+        from . import ops
+        if torch.is_tensor(imgs):
+            imgs = [imgs]
+        dev_imgs, plans = [], []
+        for img in imgs:
+            if not torch.is_tensor(img) or img.dim() not in (2, 3):
+                raise TypeError("expected (1,H,W) or (H,W) tensors")
+            if not torch.cuda.is_available():
+                raise RuntimeError("acai_omr_amd transforms run on the GPU (HIP resize kernel); there is no CPU fallback")
+            d = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+            t = img if img.is_cuda else img.to(d)
+            t = (t if t.dtype == torch.uint8 else t.to(torch.float32)).contiguous()
+            dev_imgs.append(t)
+            plans.append(self._plan(t.shape[-2], t.shape[-1]))
+        P = self.patch_size
+        dims = [(crop[2] // P, crop[3] // P) for _, crop in plans]
+        out = torch.empty(sum(h * w for h, w in dims), P * P, dtype=dtype, device=dev_imgs[0].device)
+        r0 = 0
+        for t, (size, crop) in zip(dev_imgs, plans):
+            r0 += ops.resize_to_patches(t, size, P, out, r0, crop=crop, clamp01=True)
+        return PackedPatches(out, dims, P)

@@ -83,6 +83,15 @@ int acai_patchify(const float *img, int H, int W, int P, void *out, int ld, int 
  * width pass).  C*H, OH and C <= 65535. */
 int acai_resize_bicubic_aa(const float *img, int C, int H, int W, float *tmp, float *out, int OH, int OW, int clamp01, void *stream);
 
+/* The same resize of ONE grayscale image written straight into the packed patch stream the encoder's projection GEMM reads (SURVEY 8f-2:
+ * `DynamicResize` -> `Encoder.batchify`'s Unfold, acai_omr/utils/utils.py:334-367 + acai_omr/models/models.py:48-52, without the image tensor
+ * in between): img is fp32 [H][W] in [0, 1], or uint8 (in_u8 = 1) scaled by 1/255 on load (`v2.ToDtype(torch.float32, scale=True)`,
+ * acai_omr/train/pre_train.py:56); the crop window (top, left, ch, cw) of the OH x OW result (DynamicResize's centre crop, :360-364; the whole
+ * image: 0, 0, OH, OW; ch, cw multiples of P) becomes rows row0 .. row0 + (ch/P)(cw/P) - 1 of `patches` [rows][ld >= P*P] in `out_dtype`
+ * (fp32 / bf16), row (y/P)(cw/P) + x/P, column (y%P) P + x%P as nn.Unfold(P, stride P) orders them.  tmp holds H*OW floats. */
+int acai_resize_to_patches(const void *img, int in_u8, int H, int W, float *tmp, void *patches, int ld, int row0, int OH, int OW, int top,
+                           int left, int ch, int cw, int P, int out_dtype, int clamp01, void *stream);
+
 /* out[i,:] = table[idx[i],:] (+ add[i,:]) : pos_embedding slices (M:50), nn.Embedding (M:460),
  * MAE shuffle / restore index_select (M:114,123,229). table/out fp32. */
 int acai_gather_rows(const float *table, const int32_t *idx, const float *add, float *out, int rows, int dim, void *stream);

@@ -164,25 +164,3 @@ def test_grpo_host_helpers_reference_vectors():
     msk = torch.tensor([[F, F, T], [F, F, F]])
     lx, mx = g.expand_img_latent_for_rollout(lat, msk, 2)
     assert torch.equal(lx, torch.cat([lat[:1].repeat(2, 1, 1), lat[1:].repeat(2, 1, 1)])) and torch.equal(mx, torch.cat([msk[:1].repeat(2, 1), msk[1:].repeat(2, 1)]))
-
-
-def test_sample_and_mix_seqs_reference_vectors():
-    """tests/test_vitomr.py:340-364: the first position always keeps the gold <bos> embedding; with tf_prob = 0 and hard sampling every other
-    position is the embedding of the arg-max token of the first pass (logit 100 against 5: the Gumbel noise cannot change it)."""
-    import torch
-    from conftest import VOCAB
-    from acai_omr_amd.models.models import FineTuneOMREncoder, OMRDecoder, ScheduledSamplingViTOMR
-    kw = dict(num_layers=2, num_heads=1, hidden_dim=10, mlp_dim=1)
-    torch.manual_seed(0)
-    m = ScheduledSamplingViTOMR(FineTuneOMREncoder(16, 60, 200, 1, **kw), None, OMRDecoder(1536, VOCAB, **kw))
-    V = m.decoder.vocab_embedding.weight.shape[0]
-    seqs = torch.full([1, 5], 10, dtype=torch.long)
-    seqs[:, 0] = m.decoder.bos_idx
-    logits = torch.full([1, 5, V], 5.0)
-    logits[:, :, 2] = 100.0
-    bos_emb = m.decoder.vocab_embedding(torch.tensor([m.decoder.bos_idx]))
-    mixed = m.sample_and_mix_seqs(0.8, seqs, logits, 0.1, False, "cpu")
-    assert mixed.shape == torch.Size([1, 5, m.encoder.hidden_dim]) and torch.equal(mixed[:, 0, :], bos_emb)
-    mixed = m.sample_and_mix_seqs(0, seqs, logits, 0.1, True, "cpu")
-    assert torch.equal(mixed[:, 0, :], bos_emb)
-    assert torch.equal(mixed[:, 1:, :], m.decoder.vocab_embedding(torch.tensor([2])).expand(4, -1).unsqueeze(0))

@@ -572,3 +572,37 @@ def test_decoder_positional_gradient_confined_like_reference(dev):
     opt.step()
     assert float(grad[:5].abs().sum()) > 0 and float(grad[5:].abs().sum()) == 0
     assert not torch.equal(before[:5], dec.pos_embedding.detach()[:5]) and torch.equal(before[5:], dec.pos_embedding.detach()[5:])
+
+
+@pytest.mark.gpu
+def test_sample_and_mix_seqs_reference_vectors(dev):
+    """tests/test_vitomr.py:340-364: the first position always keeps the gold <bos> embedding; with tf_prob = 0 and hard sampling every other
+    position is the embedding of the arg-max token of the first pass (logit 100 against 5: the Gumbel noise cannot change it)."""
+    import torch
+    from conftest import VOCAB
+    from acai_omr_amd.models.models import FineTuneOMREncoder, OMRDecoder, ScheduledSamplingViTOMR
+    kw = dict(num_layers=2, num_heads=1, hidden_dim=10, mlp_dim=1)
+    torch.manual_seed(0)
+    m = ScheduledSamplingViTOMR(FineTuneOMREncoder(16, 60, 200, 1, **kw), None, OMRDecoder(1536, VOCAB, **kw)).to(dev)
+    V = m.decoder.vocab_embedding.weight.shape[0]
+    seqs = torch.full([1, 5], 10, dtype=torch.long, device=dev)
+    seqs[:, 0] = m.decoder.bos_idx
+    logits = torch.full([1, 5, V], 5.0, device=dev)
+    logits[:, :, 2] = 100.0
+    bos_emb = m.decoder.vocab_embedding(torch.tensor([m.decoder.bos_idx], device=dev))
+    mixed = m.sample_and_mix_seqs(0.8, seqs, logits, 0.1, False, dev)
+    assert mixed.shape == torch.Size([1, 5, m.encoder.hidden_dim]) and torch.equal(mixed[:, 0, :], bos_emb)
+    mixed = m.sample_and_mix_seqs(0, seqs, logits, 0.1, True, dev)
+    assert torch.equal(mixed[:, 0, :], bos_emb)
+    assert torch.allclose(mixed[:, 1:, :], m.decoder.vocab_embedding(torch.tensor([2], device=dev)).expand(4, -1).unsqueeze(0), atol=1e-6)
+    # and it is differentiable in the first pass' logits and the embedding matrix (the reference trains through it, M:801-817)
+    lg = logits.clone().requires_grad_(True)
+    m.sample_and_mix_seqs(0.0, seqs, lg, 1.0, False, dev).square().sum().backward()
+    assert lg.grad is not None and float(lg.grad.abs().max()) > 0 and m.decoder.vocab_embedding.weight.grad is not None
+    # the embedding lookup itself leaves the <pad> row without gradient (nn.Embedding(padding_idx), M:409): all-gold mix of a padded sequence
+    m.zero_grad(set_to_none=True)
+    seqs2 = seqs.clone()
+    seqs2[:, -1] = m.decoder.pad_idx
+    m.sample_and_mix_seqs(1.0, seqs2, logits, 1.0, False, dev).square().sum().backward()
+    gw = m.decoder.vocab_embedding.weight.grad
+    assert float(gw[m.decoder.pad_idx].abs().max()) == 0.0 and float(gw[10].abs().max()) > 0

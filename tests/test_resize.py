@@ -150,3 +150,47 @@ def test_resize_properties_at_full_size(dev):
     mix = ops.resize_bicubic_aa((0.25 * x + 3.0 * y).contiguous(), size)
     assert (mix - (0.25 * rx + 3.0 * ry)).abs().max() < 2e-5
     assert float(rx.min()) > -0.2 and float(rx.max()) < 1.2
+
+
+@pytest.mark.gpu
+def test_resize_into_patch_stream(dev):
+    """SURVEY 8f-2, second half: `DynamicResize.to_patches` = the resize kernel's height pass writing nn.Unfold(P, P) rows of the packed stream
+    (fp32 or bf16, uint8 inputs scaled by 1/255 on load, centre crop applied) - the same rows, bit for bit, as patchify(DynamicResize(img)),
+    and an encoder fed the `PackedPatches` returns what it returns for the image tensors."""
+    from acai_omr_amd import ops
+    from acai_omr_amd.models.models import OMREncoder
+    from acai_omr_amd.utils import DynamicResize
+    g = torch.Generator().manual_seed(5)
+    P = 16
+    tr = DynamicResize(P, 512, 60, 200, True)
+    imgs = [torch.rand(1, 300, 1100, generator=g), torch.rand(1, 97, 1900, generator=g), torch.rand(1, 700, 333, generator=g)]
+    pk = tr.to_patches(imgs)
+    rows = []
+    for im in imgs:
+        r = tr(im)
+        out = torch.empty((r.shape[-2] // P) * (r.shape[-1] // P), P * P, device=dev)
+        ops.patchify(r, P, out, 0)
+        rows.append(out)
+    want = torch.cat(rows)
+    assert pk.patches.shape == want.shape and [h * w for h, w in pk.dims] == [t.shape[0] for t in rows]
+    assert torch.equal(pk.patches, want)
+    assert torch.equal(tr.to_patches(imgs, dtype=torch.bfloat16).patches, want.to(torch.bfloat16))
+    # uint8 images: ToImage's output, ToDtype(float32, scale=True) folded into the load
+    u8 = [(im * 255).round().to(torch.uint8) for im in imgs]
+    pk8 = tr.to_patches(u8)
+    want8 = tr.to_patches([t.float() / 255.0 for t in u8])
+    assert torch.equal(pk8.patches, want8.patches)
+    # a crop case: a 1:1 aspect at a large budget exceeds a small positional grid in both directions
+    tr2 = DynamicResize(P, 4096, 20, 30, True)
+    big = torch.rand(1, 900, 1000, generator=g)
+    r2 = tr2(big)
+    assert r2.shape[-2] == 20 * P and r2.shape[-1] == 30 * P
+    o2 = torch.empty(20 * 30, P * P, device=dev)
+    ops.patchify(r2, P, o2, 0)
+    assert torch.equal(tr2.to_patches([big]).patches, o2)
+    # the encoder takes the packed patches wherever it takes images
+    enc = OMREncoder(P, 60, 200, num_layers=2, hidden_dim=64, num_heads=2, mlp_dim=128).to(dev).eval()
+    with torch.no_grad():
+        a, ma = enc([tr(im) for im in imgs])
+        b, mb = enc(pk)
+    assert torch.equal(ma, mb) and torch.equal(a, b)
