@@ -67,6 +67,8 @@ class GradAllReduce:
             self._make_bucket(cur)
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._ready = [False] * len(self.buckets)
+        self._next = 0
         self._bucket_of = {}
         for bi, (_, ps) in enumerate(self.buckets):
             for p in ps:
@@ -92,6 +94,8 @@ class GradAllReduce:
                     p.grad = self._view[id(p)]
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._ready = [False] * len(self.buckets)
+        self._next = 0
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -120,7 +124,16 @@ class GradAllReduce:
                                "micro-batches of an accumulation in no_sync() and call finish() before optimizer.step()")
         self._pending[bi] += 1
         if self._pending[bi] == len(self.buckets[bi][1]):
-            self._launch(bi)
+            self._ready[bi] = True
+            self._launch_ready()
+
+    def _launch_ready(self):
+        """Collectives are matched across ranks by CALL ORDER: buckets are therefore launched strictly in index order (bucket i only after
+        0 .. i-1), whatever order backward completed them in - a rank whose shard leaves some parameter without gradient completes its buckets
+        in a different order than its peers (found by the two-rank test with one rank's branch unused: equal-sized buckets were summed crosswise)."""
+        while self._next < len(self.buckets) and self._ready[self._next]:
+            self._launch(self._next)
+            self._next += 1
 
     def _launch(self, bi):
         self._launched[bi] = True
@@ -129,22 +142,33 @@ class GradAllReduce:
 
     def finish(self):
         """Wait for the outstanding all-reduces; buckets the hooks did not complete (a parameter without gradient this step, or the last
-        backward ran under no_sync) are reduced here.  A parameter whose .grad is None keeps None: its slice is zeroed first so that stale
-        content of an earlier step is not summed into the other ranks' gradients."""
+        backward ran under no_sync) are reduced here.  A parameter whose .grad is None on THIS rank (its shard did not touch it, after a
+        zero_grad(set_to_none=True)) contributes zeros - its slice is zeroed first, so stale content of an earlier step is not summed in - and
+        afterwards RECEIVES the reduced slice as its .grad, as DistributedDataParallel does for unused parameters: otherwise the ranks that did
+        produce a gradient would take an AdamW step (weight decay, step count) that this rank skips, and the replicas would drift apart
+        silently."""
+        missing = []
         for bi, (flat, ps) in enumerate(self.buckets):
             if self._launched[bi]:
                 continue
             for p in ps:
                 if p.grad is None:
                     self._view[id(p)].zero_()
+                    missing.append(p)
                 else:
                     self._attach(p)
-            self._launch(bi)
+            self._ready[bi] = True
+        self._launch_ready()     # (in index order, as the hooks launch them)
         for h in self._handles:
             h.wait()
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            for p in missing:
+                p.grad = self._view[id(p)]
         self._handles = []
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._ready = [False] * len(self.buckets)
+        self._next = 0
 
 
 # ---- self-check of the data-parallel step on the REAL path (HIP autograd Functions + GradAllReduce + FusedAdamW) ---------------------------

@@ -328,6 +328,7 @@ class DecodeEngine:
         x = x.reshape(-1, self.E).to(device=self.device, dtype=torch.float32).contiguous()
         assert x.shape[0] == self.B, f"batch changed from {self.B} to {x.shape[0]} without prepare_caches()"
         _lib.check(_lib.lib().acai_decode_hidden(ctypes.byref(self._desc), x.data_ptr(), ops._st()), "acai_decode_hidden")
+        self._x_valid = False   # d->x now holds the caller's embedding, not the chained step's next input
         self.cache_len += 1
         return self.ws["xn"][:self.B]
 
@@ -338,6 +339,7 @@ class DecodeEngine:
         tok = tokens.reshape(-1).to(device=self.device, dtype=torch.int64).contiguous()
         assert tok.numel() == self.B, f"batch changed from {self.B} to {tok.numel()} without prepare_caches()"
         _lib.check(_lib.lib().acai_decode_logits(ctypes.byref(self._desc), tok.data_ptr(), int(time_step), ops._st()), "acai_decode_logits")
+        self._x_valid = False
         self.cache_len += 1
         return self.ws["logits"][:self.B]
 
@@ -413,6 +415,7 @@ class DecodeEngine:
         self.step.copy_(torch.tensor([1, 0], dtype=torch.int32))
         # input of the first step (<bos> at position 1, quirk Q1); each step's argmax / sampling kernel writes the next step's input
         _lib.check(_lib.lib().acai_decode_embed(ctypes.byref(self._desc), ops._st()), "acai_decode_embed")
+        self._x_valid = True
 
     STEPS_PER_GRAPH = 8   # a graph replay costs ~10-15 us of launch latency: amortise it over several decode steps
 
@@ -448,7 +451,13 @@ class DecodeEngine:
         return g
 
     def launch_steps(self, n, use_graph=True):
-        """Enqueue n decode steps on the current stream (graphs of STEPS_PER_GRAPH steps + single-step graphs for the rest)."""
+        """Enqueue n decode steps on the current stream (graphs of STEPS_PER_GRAPH steps + single-step graphs for the rest).
+        A chained step takes its input embedding from d->x, which the PREVIOUS step's argmax / sampling kernel wrote (acai_decode_step no
+        longer embeds by itself).  The stepwise entry points (logits_step / hidden_step) overwrite d->x; after one of them the input is
+        rebuilt from the device-side sequence state (`acai_decode_embed`: seqs[:, t-1] at position t) before the chain goes on."""
+        if n > 0 and not getattr(self, "_x_valid", False):
+            _lib.check(_lib.lib().acai_decode_embed(ctypes.byref(self._desc), ops._st()), "acai_decode_embed")
+            self._x_valid = True
         if not use_graph:
             st = ops._st()
             for _ in range(n):

@@ -130,7 +130,9 @@ class _ZeroArena:
         n = rows * cols
         if n >= self.CHUNK // 4:
             return torch.zeros(rows, cols, dtype=torch.float32, device=device)
-        key = (device.type, device.index)
+        # one arena per (device, stream): a chunk is zero-filled on the stream that is current when it is created, and every slice of it is
+        # consumed by a GEMM launched on that same stream (ops launch on torch's current stream), so fill and use are ordered
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
         buf, off = self._buf.get(key), self._off.get(key, 0)
         if buf is None or off + n > buf.numel():
             buf, off = torch.zeros(self.CHUNK, dtype=torch.float32, device=device), 0
@@ -139,7 +141,20 @@ class _ZeroArena:
         return buf[off:off + n].view(rows, cols)
 
 
+    def release(self):
+        """Drop the cached chunks (gradients already cut from them keep their chunk alive until they are freed themselves)."""
+        self._buf.clear()
+        self._off.clear()
+
+
 _ZEROS = _ZeroArena()
+
+
+def release_scratch():
+    """Free the zeroed weight-gradient arena's current chunks (up to 256 MB per device and stream stay cached after training ends).  Note for
+    callers that serialise gradients: a weight gradient produced by `gemm(trans_a=True, trans_w=True)` is a VIEW of a 256 MB chunk -
+    `torch.save(p.grad)` writes the whole storage; save `p.grad.clone()` instead (optimizer / model state dicts hold no gradients)."""
+    _ZEROS.release()
 
 
 def gemm(a, w, trans_a=False, trans_w=False, bias=None, residual=None, out_dtype=torch.float32, out=None):

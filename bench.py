@@ -517,6 +517,73 @@ def _leg(fn, *a, **kw):
         return dict(error=f"{type(e).__name__}: {e}")
 
 
+def dry_run(a):
+    """`--dry-run`: everything bench.py does AROUND the kernels, executed for real on the CPU with the gloo backend - the rendezvous from the
+    launcher's environment, --gpus against WORLD_SIZE, the leg selection per world size, barrier + max-over-ranks around each timed region, the
+    ragged shard deal of config 5 (`dist.shard_by_cost`), the global-count loss scaling (`dist.global_mean_scale`) and the one JSON line rank 0
+    prints - so that the first multi-GPU run of the driver does not meet an untested code path there.  Every measured quantity is a stand-in."""
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    dev = torch.device("cpu")
+    legs = set((a.legs.split(",") if a.legs is not None else (["e2e", "b1", "mae", "tf", "ragged"] if world == 1 else ["mae", "config5"])))
+    legs.discard("")
+    if a.no_mae:
+        legs.discard("mae")
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+
+    def timed(fn, n):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        sync()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    dt = timed(lambda: time.sleep(1e-4), a.steps)
+    S = (a.height // 16) * (a.width // 16)
+    out = dict(metric="LMX tokens/sec (greedy decode, KV cache)", value=world * a.batch * a.steps / dt, unit="tokens/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+               ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic", dry_run=True,
+               config=dict(workload=f"DRY RUN (no kernels): vitomr_greedy_decode batch {a.batch}/GPU of {a.height}x{a.width} images ({S} patches)", batch_per_gpu=a.batch,
+                           memory_len=S, decoder="12 x d1024 h16 mlp4096, V=227", hipgraph=True),
+               roofline=None, cpu_baseline=None, mae=None, tf_step=None, ragged_decode=None, config5=None, end_to_end=None, latency_b1=None)
+    if "mae" in legs:
+        d = timed(lambda: time.sleep(1e-4), a.mae_steps)
+        out["mae"] = dict(images_per_s=world * a.mae_batch * a.mae_steps / d, ms_per_step=d / a.mae_steps * 1e3, batch_per_gpu=a.mae_batch, dtype=a.mae_dtype, dry_run=True)
+    for key, name in (("tf", "tf_step"), ("ragged", "ragged_decode"), ("e2e", "end_to_end"), ("b1", "latency_b1")):
+        if key in legs and world == 1:
+            out[name] = dict(dry_run=True)
+    if "config5" in legs:
+        from acai_omr_amd.dist import global_mean_scale, shard_by_cost
+        shapes = [CONFIG4_SHAPES[i % 8] for i in range(32 * world)]
+        costs = [h * w // 256 for h, w in shapes]
+        shards = shard_by_cost(costs, world)
+        mine = shards[rank]
+        scale = float(global_mean_scale(float(sum(costs[i] for i in mine)), device=dev)) if dist is not None else 1.0
+        tot = torch.tensor([scale], dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(tot)      # the local / global count fractions of all ranks sum to one
+        out["config5"] = dict(config=f"DRY RUN: global batch {32 * world} ragged images dealt by cost, {len(mine)} on rank 0 ({sum(costs[i] for i in mine)} patches)",
+                              images_global=32 * world, shard_sizes=[len(s) for s in shards], shard_patches=[sum(costs[i] for i in s) for s in shards],
+                              count_fractions_sum=float(tot.item()), mae=dict(dry_run=True), tf_step=dict(dry_run=True), dp_parity_max_abs_diff=None, dp_parity_ok=None)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -534,7 +601,11 @@ def main():
     ap.add_argument("--legs", default=None, help="comma list of e2e,b1,mae,tf,ragged,config5 (default: e2e,b1,mae,tf,ragged at N = 1; mae,config5 at N > 1)")
     ap.add_argument("--no-mae", action="store_true")
     ap.add_argument("--leg-timeout", type=float, default=420.0, help="seconds the secondary legs may take before the line is printed without them")
+    ap.add_argument("--dry-run", action="store_true", help="control flow only, on the CPU over gloo: argument parsing, rank / leg selection, the collectives "
+                    "around the timed regions and the JSON line's shape, with stand-in numbers (no kernel runs; `dry_run: true` marks the line)")
     a = ap.parse_args()
+    if a.dry_run:
+        return dry_run(a)
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"

@@ -220,9 +220,12 @@ typedef struct {
 /* Input of the FIRST step after the device-side loop state was armed: x = vocab_embedding[seqs[:, t-1]] + pos_embedding[t], t = step[0]
  * (M:521-524 with quirk Q1).  Every later step's input is written by the previous step's argmax / sampling kernel. */
 int acai_decode_embed(const AcaiDecoder *dec, void *stream);
-/* One greedy step t = *step for all B rows: embed seqs[:,t-1] with pos_embedding[t] (quirk Q1, M:576),
- * 12x cached_forward, final norm, unembed, argmax + log_softmax gather, seqs[:,t] / logprobs[:,t] update,
- * finished flags, ++*step.  Enqueues only kernels: capture it in a hipGraph and replay. */
+/* One greedy step t = *step for all B rows: input x = embedding of seqs[:,t-1] at pos_embedding[t] (quirk Q1, M:576), 12x cached_forward,
+ * final norm, unembed, argmax + log_softmax gather, seqs[:,t] / logprobs[:,t] update, finished flags, ++*step.  Enqueues only kernels:
+ * capture it in a hipGraph and replay.
+ * CONTRACT (E % 4 == 0): the step does NOT embed its own input - dec->x must hold it: written by acai_decode_embed after arming, and by every
+ * step's argmax / sampling kernel for the next one.  acai_decode_logits and acai_decode_hidden overwrite dec->x: after either, call
+ * acai_decode_embed again before the next acai_decode_step / acai_decode_sample_step (the Python engine tracks this itself). */
 int acai_decode_step(const AcaiDecoder *dec, void *stream);
 /* One SAMPLING decode step for every sequence (GRPOViTOMR.cached_forward_rollout_policy, acai_omr/models/models.py:988-1049): as
  * acai_decode_step, but the next token is drawn from softmax(top_k(logits) / temperature) and its log-probability is taken under

@@ -124,6 +124,44 @@ def gen_mae_surface():
     print("mae_surface.pt: batchify", tuple(out["batchify"]["embeddings"].shape), "prepare_for_decoder", tuple(out["prepare_for_decoder"]["out"].shape))
 
 
+def gen_distinct_rows(name="vitomr_dh64b"):
+    """A d_h = 64 ViTOMR fixture whose two images decode to DIFFERENT token rows (round-2 verdict: in `vitomr_dh64` both rows are the same ten
+    tokens - the scaled unembed dominates the logits there - so a token check barely sees the cross-attention).  Same generator as the
+    other ViTOMR fixtures (oracle/gen_golden.py: gen_vitomr, incl. its oracle == reference asserts) with the decoder's cross-attention output
+    projections scaled up at construction; seeds are tried until the rows differ in at least half of their positions and the oracle's
+    autocast restatement lands on the reference's bf16 tokens."""
+    import gen_golden as G
+    dh64 = dict(P=16, pe_h=4, pe_w=8, ft_depth=2, enc_layers=2, enc_dim=128, enc_heads=2, enc_mlp=256, head_dim=256,
+                dec_layers=2, dec_dim=128, dec_heads=2, dec_mlp=256, max_len=24, gen_len=12, lmx_lens=[7, 4])
+    g = torch.Generator().manual_seed(777)
+    imgs = [torch.rand(1, 32, 64, generator=g), torch.rand(1, 64, 128, generator=g), torch.rand(1, 48, 96, generator=g)]
+    plain_build = G.build_vitomr
+
+    def build(cfg, dropout_zero=False):
+        m = plain_build(cfg, dropout_zero)
+        with torch.no_grad():
+            for ly in m.decoder.decoder_blocks.layers:
+                ly.multihead_attn.out_proj.weight.mul_(8.0)
+        return m
+
+    G.build_vitomr = build
+    try:
+        for seed in range(300, 340):
+            G.gen_vitomr(name, dh64, imgs, seed)
+            fx = torch.load(os.path.join(OUT, name + ".pt"), map_location="cpu", weights_only=False)
+            rows = fx["ref_bf16"]["seqs"]
+            diff01 = float((rows[0] != rows[1]).float().mean()), float((rows[0] != rows[2]).float().mean())
+            same32 = torch.equal(fx["ref_fp32"]["seqs"], fx["ref_bf16"]["seqs"])
+            print(f"seed {seed}: rows differ in {diff01} of their positions; oracle bf16 tokens equal = {fx['oracle_bf16_tokens_equal']}; fp32 == bf16 tokens {same32}")
+            if min(diff01) >= 0.5 and fx["oracle_bf16_tokens_equal"]:
+                print("kept seed", seed, rows.tolist())
+                return
+        raise SystemExit("no seed gave distinct rows")
+    finally:
+        G.build_vitomr = plain_build
+
+
 if __name__ == "__main__":
     gen_surface_json()
     gen_mae_surface()
+    gen_distinct_rows()

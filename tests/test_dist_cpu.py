@@ -208,3 +208,70 @@ def test_training_loops_under_two_ranks_match_single_process(tmp_path):
         assert torch.allclose(a, b.detach(), atol=2e-5), float((a - b.detach()).abs().max())
     for a, b in zip(p2, m2.parameters()):
         assert torch.allclose(a, b.detach(), atol=2e-5), float((a - b.detach()).abs().max())
+
+
+def _worker_unused(rank, world, port, out):
+    """Rank 1's shard never touches the second branch of the model: after optimizer.zero_grad(set_to_none=True) its .grad there is None."""
+    sys.path.insert(0, ROOT)
+    from acai_omr_amd.dist import GradAllReduce
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    a, b = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)
+    model = torch.nn.ModuleList([a, b])
+    ddp = GradAllReduce(model, bucket_mb=0.00005)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, weight_decay=0.1)
+    x = torch.ones(3, 4) * (rank + 1)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        y = a(x).sum() + (b(x).sum() if rank == 0 else 0.0)
+        y.backward()
+        ddp.finish()
+        assert all(p.grad is not None for p in model.parameters()), "every rank must step every parameter"
+        opt.step()
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        torch.save(gathered, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_parameter_without_gradient_on_one_rank_stays_in_step(tmp_path):
+    """a parameter whose .grad is None on one rank received zeros in the all-reduce but kept None, so that rank skipped the AdamW
+    step (weight decay, step count) the others took.  finish() now hands it the reduced slice: the replicas stay identical."""
+    out = str(tmp_path / "u.pt")
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_worker_unused, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out)
+    assert torch.equal(r0, r1)
+
+
+def test_bench_dry_run_two_ranks():
+    """`bench.py --gpus 2 --dry-run` under torch.distributed.run (gloo, CPU): the launcher contract, the leg selection at N > 1 and the JSON
+    line's keys, incl. config 5's shard deal - what the driver's first multi-GPU run exercises around the kernels."""
+    import json
+    import subprocess
+    port = 33500 + os.getpid() % 2000
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                        str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout      # ONE line, from rank 0
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "mae", "config5"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["dry_run"] is True and "workload" in d["config"]
+    assert d["tf_step"] is None and d["ragged_decode"] is None            # single-GPU legs are not run at N > 1
+    c5 = d["config5"]
+    assert c5["images_global"] == 64 and c5["shard_sizes"] == [32, 32] and abs(c5["count_fractions_sum"] - 1.0) < 1e-12
+    assert abs(c5["shard_patches"][0] - c5["shard_patches"][1]) <= 1024   # cost-balanced deal of the ragged shapes
+    # and the single-process form selects the single-GPU legs
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "3"], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    d1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
+    assert d1["n_gpus"] == 1 and d1["config5"] is None and d1["end_to_end"] is not None and d1["latency_b1"] is not None and d1["tf_step"] is not None

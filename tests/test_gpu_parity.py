@@ -40,7 +40,7 @@ def build_vitomr(cfg, sd, dev, cache_dtype, max_batch=8):
     return m.to(dev).eval()
 
 
-@pytest.mark.parametrize("name", ["vitomr_small", "vitomr_dh64", "vitomr_odd"])
+@pytest.mark.parametrize("name", ["vitomr_small", "vitomr_dh64", "vitomr_dh64b", "vitomr_odd"])
 def test_fp32_encoder_head_greedy_vs_reference_golden(dev, name):
     fx = load_golden(name)
     cfg, ref = fx["cfg"], fx["ref_fp32"]
@@ -69,7 +69,7 @@ def test_fp32_encoder_head_greedy_vs_reference_golden(dev, name):
             assert md(lg.squeeze(1), ref["step_logits"][:, t - 1]) < 1e-3, t
 
 
-@pytest.mark.parametrize("name", ["vitomr_small", "vitomr_dh64", "vitomr_odd"])
+@pytest.mark.parametrize("name", ["vitomr_small", "vitomr_dh64", "vitomr_dh64b", "vitomr_odd"])
 def test_bf16_inference_entry_point_vs_reference_and_oracle(dev, name):
     from acai_omr_amd.inference.vitomr_inference import inference
     from oracle import vitomr_oracle as O
@@ -569,3 +569,34 @@ def test_full_size_batch_independence_of_mae(dev):
             n = p1.shape[1]
             assert torch.equal(lm1[0], lm[b, :n]) and torch.equal(t1[0], tgt[b, :n])
             assert (p1[0] - pred[b, :n]).abs().max() < 2e-4
+
+
+def test_chained_steps_after_a_stepwise_call_reembed_their_input(dev):
+    """acai_decode_step takes its input from dec->x (written by the previous step's argmax kernel); the stepwise entry point
+    (OMRDecoder.cached_generate -> acai_decode_logits) overwrites dec->x.  Mixing them must not decode from a stale input: the engine re-embeds
+    from the device-side sequence state.  Greedy decode of the first tokens == decode where one step is taken through cached_generate."""
+    fx = load_golden("vitomr_small")
+    cfg = fx["cfg"]
+    m = build_vitomr(cfg, fx["state_dict"], dev, torch.float)
+    with torch.no_grad():
+        lat, mask = m.encoder(fx["imgs"])
+        mem = m.transition_head(lat)
+        ref, _, _ = m.cached_greedy_generate(mem, mask, max_len=cfg["gen_len"])
+        # same decode, driven by hand: arm, 3 chained steps, one stepwise call (which overwrites dec->x), then chained steps again
+        blocks = m.decoder.decoder_blocks
+        from acai_omr_amd import engine as EG
+        packed, lens = EG.unpad_rows(mem, mask)
+        blocks.prepare_caches_packed(packed, None, lens)
+        eng = blocks.engine(packed.device)
+        with torch.cuda.stream(eng.stream):
+            eng.arm(eng.B)
+            eng.launch_steps(3, use_graph=False)
+            torch.cuda.synchronize()
+            eng.ws["x"].fill_(123.0)          # what a stepwise call leaves behind: someone else's input
+            eng._x_valid = False
+            eng.launch_steps(cfg["gen_len"] - 1 - 3, use_graph=False)
+            torch.cuda.synchronize()
+        got = eng.seqs[:eng.B, :cfg["gen_len"]].clone()
+    n = ref.shape[1]
+    live = m.create_inference_mask(got)[:, :n]
+    assert torch.equal(got[:, :n].masked_fill(~live, m.decoder.pad_idx).cpu(), ref.cpu())

@@ -12,7 +12,7 @@ def md(a, b):
     return float((a.float() - b.float()).abs().max())
 
 
-@pytest.mark.parametrize("name", ["vitomr_small", "vitomr_dh64", "vitomr_odd"])
+@pytest.mark.parametrize("name", ["vitomr_small", "vitomr_dh64", "vitomr_dh64b", "vitomr_odd"])
 def test_encoder_head_decode_fp32(name):
     fx = load_golden(name)
     cfg, sd, ref = fx["cfg"], fx["state_dict"], fx["ref_fp32"]
@@ -32,7 +32,7 @@ def test_encoder_head_decode_fp32(name):
     assert md(logits[:, :ref["step_logits"].shape[1]], ref["step_logits"]) < 1e-4  # well inside the 1e-3 bar
 
 
-@pytest.mark.parametrize("name", ["vitomr_small", "vitomr_dh64", "vitomr_odd"])
+@pytest.mark.parametrize("name", ["vitomr_small", "vitomr_dh64", "vitomr_dh64b", "vitomr_odd"])
 def test_decode_bf16_autocast_plumbing(name):
     """inference() plumbing: fp32 encoder, autocast(bf16) head + decode with a bf16 KV cache."""
     fx = load_golden(name)
