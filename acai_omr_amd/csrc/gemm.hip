@@ -1241,16 +1241,20 @@ __device__ __forceinline__ void pp_swap2(uint32_t &x, uint32_t &y) {
 }
 // MODE (compile-time: one kernel instantiation per epilogue form - with every form in one body the kernel was > 100 KB of code, more than the
 // instruction cache, and a plain bf16 epilogue took ~10 us per tile walking around the other forms' blocks)
-enum { PP_OBF = 1, PP_GELU = 2, PP_AUX1 = 4, PP_AUX2 = 8, PP_RES = 16, PP_SCALE = 32 };
+enum { PP_OBF = 1, PP_GELU = 2, PP_AUX1 = 4, PP_AUX2 = 8, PP_RES = 16, PP_SCALE = 32, PP_DEFER = 64 };
 template <int MODE>
-__device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 (&acc)[8][4], int m0, int n0, int lane, float bv) {
+__device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 (&acc)[8][4], int m0, int n0, int lane, float bv, void *dst = nullptr,
+                                                 int ldd = 0) {
     const int lm = lane & 15, lq = lane >> 4;
     constexpr bool obf = MODE & PP_OBF, do_gelu = MODE & PP_GELU, has_res = MODE & PP_RES, has_scale = MODE & PP_SCALE;
     constexpr int aux_mode = (MODE & PP_AUX1) ? 1 : ((MODE & PP_AUX2) ? 2 : 0);
     const bool do_round = g.flags & ACAI_GEMM_ROUND_BF16;
     const bool pre_round = do_round && (do_gelu || aux_mode != 0 || has_res || !obf);
     constexpr int es = obf ? 2 : 4;
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)((size_t)g.M * g.ldc * es), 0x00020000);
+    // (dst / ldd: the deferred forms write their first, plain bf16 pass somewhere else than C - see gemm_nt_pp_kernel)
+    void *const Cp = dst ? dst : g.C;
+    const int ldc = dst ? ldd : g.ldc;
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(Cp, 0, (int)((size_t)g.M * ldc * es), 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(has_res ? g.residual : reinterpret_cast<const float *>(g.C)), 0,
                                                                         has_res ? (int)((size_t)g.M * g.ldr * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(aux_mode ? g.aux : g.C, 0, aux_mode ? (int)((size_t)g.M * g.ldaux * es) : 0, 0x00020000);
@@ -1307,7 +1311,7 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
             const bool rowok = row < g.M;
             f32x4 v[2];
             const bool swok = rowok && (sw_col + p * 32) < g.N;
-            const uint32_t off_sw_c = swok ? (uint32_t)(((size_t)row * g.ldc + sw_col + p * 32) * 2) : OOB;
+            const uint32_t off_sw_c = swok ? (uint32_t)(((size_t)row * ldc + sw_col + p * 32) * 2) : OOB;
             const uint32_t off_sw_x = swok ? (uint32_t)(((size_t)row * g.ldaux + sw_col + p * 32) * 2) : OOB;
             float a0[2][4] = {};
             if constexpr (aux_mode == 2) {
@@ -1373,7 +1377,7 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
                 }
                 if constexpr (has_res) v[t] += __builtin_bit_cast(f32x4, prer[mb][t]);
                 if constexpr (!obf) {
-                    const uint32_t o = (rowok && colok[nb]) ? (uint32_t)(((size_t)row * g.ldc + col) * 4) : OOB;
+                    const uint32_t o = (rowok && colok[nb]) ? (uint32_t)(((size_t)row * ldc + col) * 4) : OOB;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[t]), rc, o, 0, 0);
                 }
             }
@@ -1470,8 +1474,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     };
     int a_done = 0, w_done = 0;
     auto next_slot = [&]() { p_slot = p_slot == NSLOT - 1 ? 0 : p_slot + 1; };
-    auto issue_a = [&]() {
-        if (a_done >= total) return;
+    auto issue_a = [&]() -> bool {
+        if (a_done >= total) return false;
         const uint32_t lb = lds_base + p_slot * UNIT;
         const T *base = tileA + (size_t)a_kt * BK;   // uniform
         if (!(dbg & 2)) glds16s_x4(__builtin_amdgcn_readfirstlane(lb + wave * 4096), base, offA[0], offA[1], offA[2], offA[3]);
@@ -1481,9 +1485,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
         }
         ++a_done;
         next_slot();
+        return true;
     };
-    auto issue_w = [&]() {
-        if (w_done >= total) return;
+    auto issue_w = [&]() -> bool {
+        if (w_done >= total) return false;
         const uint32_t lb = lds_base + p_slot * UNIT;
         const T *base = tileW + (size_t)w_kt * BK;
         if (!(dbg & 2)) glds16s_x4(__builtin_amdgcn_readfirstlane(lb + wave * 4096), base, offW[0], offW[1], offW[2], offW[3]);
@@ -1493,6 +1498,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
         }
         ++w_done;
         next_slot();
+        return true;
     };
 
     // ---- consumer: swapped 16x16x32 MFMAs; lane (lm, lq) of accumulator [mb][nb] holds C[mb*16 + lm][nb*16 + 4*lq + 0..3] ----
@@ -1538,7 +1544,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     auto wait_step = [&](int allow) {
         switch (allow) {
             case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
             case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
             case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
             case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
             case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
@@ -1551,17 +1566,88 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     // The bias of the tile in flight, one column per lane (lane L: bias[bn0 + wn*64 + L]); the epilogue distributes it with ds_bpermute and
     // issues no vector-memory load of its own.  A compiler-visible load anywhere in this loop is waited for with vmcnt(0) at its first use,
     // i.e. behind whatever LDS-DMA is in flight then (vmcnt counts in order): 2.5-3.6 us per tile, measured at three placements.  So the load is
-    // an asm statement the wait-count pass does not see, issued in the tile's FIRST K-step in front of that step's LDS-DMA; the counted wait at
-    // the end of the same K-step retires it together with everything older than W(q+1), and its first use is at least one barrier later.  The
-    // register is tied in and out of the asm ("+v"): no copy of it can be scheduled between the issue and the wait.
-    uint32_t bvr = 0;
+    // an asm statement the wait-count pass does not see, issued in front of the K-step's LDS-DMA; the counted wait at the end of the same K-step
+    // retires it together with everything older than W(q+1), and it is read at the top of the NEXT K-step.
+    // Rule for every such untracked load in this kernel (bias, deferred chunks): ONE load statement and ONE take statement per loop iteration,
+    // both unconditional and in straight-line code, the value handed from the load's "=v" output to the take's "+v" operand.  A first version
+    // loaded under `if (tile start)` into a register tied through the asm statements: the branches' merge points made the register allocator
+    // copy the value right behind the load statement - i.e. read it before the data had landed.  (Accumulator registers as destinations would
+    // be out of the compiler's reach, but a kernel that touches AGPRs gets its 256 registers split 128 / 128 on gfx950: 100+ spills here.)
+    uint32_t bias_raw = 0;
     int c_tile = 0, c_kt = 0, slot_a = 0;
-    auto load_bias = [&]() {
+    auto load_bias = [&]() {      // this K-step's tile
         int bm0, bn0;
-        tile_origin(c_tile, bm0, bn0);
+        tile_origin(c_tile < n_my ? c_tile : n_my - 1, bm0, bn0);
         const uint32_t off = (uint32_t)min(bn0 + wn * 64 + lane, g.N - 1) * 4;
-        asm volatile("global_load_dword %0, %1, %2" : "+v"(bvr) : "v"(off), "s"(g.bias) : "memory");
+        const float *bp = g.bias ? g.bias : reinterpret_cast<const float *>(g.W);   // (no bias: any valid address; the value is not used)
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(bias_raw) : "v"(g.bias ? off : 0u), "s"(bp) : "memory");
     };
+    // ---- PP_DEFER: the expensive half of a GELU epilogue leaves the tile boundary -----------------------------------------------------------
+    // The GELU forms (forward: C = gelu(a), aux = a; backward: C = v gelu'(aux)) spend ~10k cycles of VALU per wave and tile at the boundary,
+    // beside ONE 512-cycle MFMA segment of the partner wave: 2 x 10k exposed per tile against 16k of MFMA time (K = 512).  Deferred form: the
+    // boundary epilogue only stores the bf16-rounded linear output (a into aux / v into C - both are rounded to bf16 before the GELU step in
+    // the undeferred arithmetic too, so nothing changes numerically), and the GELU step runs in CHUNKS of 8 columns x 16 rows per lane - one
+    // 16-byte piece of the SAME lane's own stores, read back from L2 - one chunk per R segment of the next tile, i.e. beside the partner's MFMAs
+    // for the whole tile.  A chunk's piece is loaded one segment ahead by an untracked asm load (as the bias is: a compiler-visible load would be
+    // waited for behind the LDS-DMA in flight), in FRONT of that segment's LDS-DMA, so waiting for it (vmcnt(4): only the DMA pieces are
+    // younger) never waits for a DMA.
+    // MEASURED (round 3, tools/bench_pp.py, same box): slower - MAE decoder lin1 + GELU 833 against 686 us, its gelu' GEMM 962 against 825 us,
+    // the encoder's 283 / 304 against 236 / 254 us.  A chunk is ~1100 cycles of VALU in an R segment whose partner's M segment is 512: every
+    // barrier interval stretches to the chunk, 32 intervals per tile, where the boundary form pays its 2 x 10k once - the two waves of a SIMD
+    // share one VALU port, so 20k VALU cycles per SIMD and tile cannot hide behind 16k of MFMA however they are cut - and the chunks come back
+    // from L2 / MALL (0.8 GB more reads on lin1).  Off by default (variant 8 / ACAI_GEMM_PP_DEFER=1 select it); the test keeps it runnable.
+    constexpr bool DEFER = MODE & PP_DEFER;
+    constexpr int NL = (MODE & PP_AUX2) ? 2 : 1;     // loads per chunk
+    // two chunk slots: X is loaded in R(q,0) and finished in R(q,1), Y is loaded in R(q,1) and finished in R(q+1,0); *2: the saved
+    // pre-activation of the backward form.  Loads and takes are unconditional (an idle slot reloads chunk 0 and drops its result), see the rule
+    // at the bias load.
+    u32x4_t cX = {0, 0, 0, 0}, cX2 = {0, 0, 0, 0}, cY = {0, 0, 0, 0}, cY2 = {0, 0, 0, 0};
+    int d_m0 = 0, d_n0 = 0, d_next = 16;   // tile being drained (its wave block's origin) and its next chunk to load (16: nothing to drain)
+    int idX = -1, idY = -1;                // chunk id in each slot (-1: idle)
+    // one chunk per R segment: a tile has 2 nkt of them for its predecessor's 16 chunks (host: nkt >= 8, i.e. K >= 512 - every MLP of the path)
+    const __amdgpu_buffer_rsrc_t d_rc = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)((size_t)g.M * g.ldc * 2), 0x00020000);
+    auto chunk_off = [&](int c, int ld, bool &ok) -> uint32_t {
+        const int row = d_m0 + (c & 7) * 16 + lm, col = d_n0 + (lq & 1) * 16 + (lq >> 1) * 8 + (c >> 3) * 32;
+        ok = c >= 0 && row < g.M && col < g.N;
+        return ok ? (uint32_t)row * (uint32_t)(ld * 2) + (uint32_t)col * 2 : 0u;
+    };
+    auto chunk_load = [&](int c, u32x4_t &L, u32x4_t &A2) {
+        bool ok;
+        if constexpr (MODE & PP_AUX2) {
+            const uint32_t oc = chunk_off(c, g.ldc, ok), ox = chunk_off(c, g.ldaux, ok);
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(L) : "v"(oc), "s"(g.C) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(A2) : "v"(ox), "s"(g.aux) : "memory");
+        } else {
+            const uint32_t ox = chunk_off(c, g.ldaux, ok);
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(L) : "v"(ox), "s"(g.aux) : "memory");
+        }
+    };
+    // wait for the slot's loads: only the LDS-DMA pieces issued behind them (four, or none at the end of the work list) may stay outstanding
+    auto chunk_take = [&](bool dma_behind, u32x4_t &L, u32x4_t &A2) {
+        // (the statement that carries the registers is unconditional: with one take per branch the merge point copied the in-flight registers)
+        if (!dma_behind) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (MODE & PP_AUX2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(L), "+v"(A2)::"memory");
+        else asm volatile("s_waitcnt vmcnt(4)" : "+v"(L)::"memory");
+    };
+    auto chunk_finish = [&](int c, const u32x4_t &L, const u32x4_t &A2) {
+        bool ok;
+        const uint32_t oc = chunk_off(c, g.ldc, ok);
+        u32x4_t o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float lo = __uint_as_float(L[i] << 16), hi = __uint_as_float(L[i] & 0xFFFF0000u);
+            if constexpr (MODE & PP_AUX2) {
+                lo *= gelu_erf_grad(__uint_as_float(A2[i] << 16));
+                hi *= gelu_erf_grad(__uint_as_float(A2[i] & 0xFFFF0000u));
+            } else {
+                lo = gelu_erf(lo);
+                hi = gelu_erf(hi);
+            }
+            o[i] = pack_bf16(lo, hi);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(o, d_rc, ok ? oc : 0xFFFFFFF0u, 0, 0);
+    };
+
     set_a(0);
     set_w(0);
     issue_a();   // A(0)
@@ -1575,24 +1661,50 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
         for (int i = 0; i < (int)(blockIdx.x / 8 % 8); ++i) __builtin_amdgcn_s_sleep(32);   // ~ (w/8 % 8) x 1 us
     }
     if (grp == 1) PP_BAR();   // G1 runs one segment behind
+    bool dma_prev = true;    // the segment before the first one of the loop issued A(1)
     for (int q = 0; q <= total; ++q) {
         const bool live = q < total;    // the extra pass q == total only runs the last tile's epilogue (and keeps the barrier count)
         const int slot_w = slot_a == NSLOT - 1 ? 0 : slot_a + 1;
         const unsigned char *sa = lds + slot_a * UNIT, *sb = lds + slot_w * UNIT;
         // ---- R(q, 0) ----
-        float bv = __uint_as_float(bvr);    // the finished tile's bias (its load was retired K-steps ago), before the next tile's load reuses the register
-        if (!live) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv)::"memory");   // (a single-K-step last tile: no counted wait came after its load)
-        if (live && c_kt == 0 && g.bias) load_bias();
-        issue_w();   // W(q+1) -> the slot A(q-1) left
+        const bool boundary = c_kt == 0 && q > 0;
+        if (!live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no counted wait came after the last K-step's bias / chunk loads)
+        asm volatile("" : "+v"(bias_raw));   // take: the load of the K-step before was retired by that K-step's counted wait
+        const float bv = g.bias ? __uint_as_float(bias_raw) : 0.f;
         int allow = q + 2 < total ? 4 : 0;
-        if (c_kt == 0 && q > 0) {
-            int bm0, bn0;
-            tile_origin(c_tile - 1, bm0, bn0);
-            if (!(dbg & 4)) {
-                gemm_pp_epilogue<MODE>(g, acc, bm0 + wm * 128, bn0 + wn * 64, lane, g.bias ? bv : 0.f);
-                allow += n_st;
+        if constexpr (DEFER) {
+            // slot Y (loaded in R(q-1,1), in front of A(q+1)'s pieces): take and finish - at a tile boundary this is the old tile's last chunk
+            chunk_take(live && dma_prev, cY, cY2);
+            if (idY >= 0) chunk_finish(idY, cY, cY2);
+            if (boundary) {
+                // the plain bf16 pass of the tile just finished; its chunks start below
+                int bm0, bn0;
+                tile_origin(c_tile - 1, bm0, bn0);
+                if (!(dbg & 4)) {
+                    if constexpr (MODE & PP_AUX2) gemm_pp_epilogue<PP_OBF>(g, acc, bm0 + wm * 128, bn0 + wn * 64, lane, bv);
+                    else gemm_pp_epilogue<PP_OBF>(g, acc, bm0 + wm * 128, bn0 + wn * 64, lane, bv, g.aux, g.ldaux);
+                }
+                zero_acc();
+                d_m0 = bm0 + wm * 128;
+                d_n0 = bn0 + wn * 64;
+                d_next = 0;
             }
-            zero_acc();
+            load_bias();
+            idX = (live && d_next < 16) ? d_next++ : -1;
+            chunk_load(idX, cX, cX2);
+            dma_prev = issue_w();   // W(q+1) -> the slot A(q-1) left
+        } else {
+            load_bias();
+            issue_w();   // W(q+1) -> the slot A(q-1) left
+            if (boundary) {
+                int bm0, bn0;
+                tile_origin(c_tile - 1, bm0, bn0);
+                if (!(dbg & 4)) {
+                    gemm_pp_epilogue<MODE>(g, acc, bm0 + wm * 128, bn0 + wn * 64, lane, bv);
+                    allow += n_st;
+                }
+                zero_acc();
+            }
         }
         if (live && !(dbg & 16)) reads(sa, sb, offk0);   // (after the epilogue: the fragment registers are not live across it)
         PP_LGKM0();
@@ -1601,7 +1713,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
         if (live && !(dbg & 8)) mfmas();
         PP_BAR();
         // ---- R(q, 1) ----
-        issue_a();   // A(q+2) -> the slot W(q-1) left (the K-step's eight LDS-DMA pieces are split over its two R segments)
+        if constexpr (DEFER) {
+            chunk_take(dma_prev, cX, cX2);   // slot X, loaded in R(q,0) in front of W(q+1)'s pieces
+            if (idX >= 0) {
+                chunk_finish(idX, cX, cX2);
+                allow += 1;                  // its store is younger than W(q+1) ...
+            }
+            idY = (live && d_next < 16) ? d_next++ : -1;
+            chunk_load(idY, cY, cY2);
+            allow += NL;                     // ... and so are slot Y's loads
+            dma_prev = issue_a();            // A(q+2) -> the slot W(q-1) left
+        } else {
+            issue_a();   // A(q+2) -> the slot W(q-1) left (the K-step's eight LDS-DMA pieces are split over its two R segments)
+        }
         if (live && !(dbg & 16)) reads(sa, sb, offk1);
         PP_LGKM0();
         if (grp == 1 && q + 1 < total && !(dbg & 1)) wait_step(allow);
@@ -1619,6 +1743,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     if (grp == 0) PP_BAR();
 #undef PP_BAR
 #undef PP_LGKM0
+    if constexpr (DEFER) {
+        // the last tile's chunks: nothing else is in flight any more, so plain (compiler-tracked) loads, all requested before the first is used
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(g.aux, 0, (int)((size_t)g.M * g.ldaux * 2), 0x00020000);
+        u32x4_t Ls[16], As[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            bool ok;
+            if constexpr (MODE & PP_AUX2) {
+                Ls[c] = __builtin_amdgcn_raw_buffer_load_b128(d_rc, chunk_off(c, g.ldc, ok), 0, 0);
+                As[c] = __builtin_amdgcn_raw_buffer_load_b128(rx, chunk_off(c, g.ldaux, ok), 0, 0);
+            } else {
+                Ls[c] = __builtin_amdgcn_raw_buffer_load_b128(rx, chunk_off(c, g.ldaux, ok), 0, 0);
+                As[c] = Ls[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) chunk_finish(c, Ls[c], As[c]);
+    }
 }
 
 // ---- dW = dY^T X on the three-stage ring (round 2) -------------------------------------------------------------------------------------
@@ -1980,7 +2123,8 @@ int launch(const GemmArgs &g, hipStream_t st) {
     }
     if (fast && !TA && !TB && g.K % BKG == 0 && !no_glds) {
         // Row-major LDS-DMA kernels.  variant (acai_gemm_set_variant / ACAI_GEMM_VARIANT; tests and A/B runs): 0 auto, 1 128x128 two-stage,
-        // 2 256x128 two-stage, 3 256x128 three-stage, 4 256x128 persistent three-stage ring, 5 256x256 two-stage.
+        // 2 256x128 two-stage, 3 256x128 three-stage, 4 256x128 persistent three-stage ring, 5 256x256 two-stage, 6 persistent 256x256 ring of
+        // half-stages, 7 ping-pong ring with the register epilogue, 8 = 7 with the GELU forms' deferred epilogue.
         static const int n_cu = [] {
             int dev = 0, n = 256;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
@@ -1988,6 +2132,11 @@ int launch(const GemmArgs &g, hipStream_t st) {
         }();
         const int nwg4 = cdiv(g.M, 256) * cdiv(g.N, BN), nwg256 = cdiv(g.M, 256) * cdiv(g.N, 256);
         int v = g_gemm_variant;
+        bool defer = false;   // variant 8 = 7 with the GELU forms' deferred epilogue (PP_DEFER: measured slower, kept as an experiment - see there)
+        if (v == 8) {
+            v = 7;
+            defer = true;
+        }
         // auto (tools/bench_gemm.py, bf16): up to 24 K-tiles the persistent ring wins (0.61-0.71 PF on K = 512..768 against 0.53-0.64 for
         // one tile per workgroup); from 64 K-tiles the 256x256 tile does (1.00-1.02 PF at 4096^3 / 8192^3 against 0.95-0.98); between, the
         // three-stage 256x128 kernel; small problems keep two 128x128 workgroups per CU.
@@ -2040,8 +2189,15 @@ int launch(const GemmArgs &g, hipStream_t st) {
                 if constexpr (sizeof(T) == 2 && EPI == 0) {
                     if (const char *d = getenv("ACAI_GEMM_DEBUG")) h.flags |= atoi(d) << 8;
                     const dim3 grid(nwg256 < n_cu ? nwg256 : n_cu), block(512);
-                    switch (pp_mode(h)) {
+                    int mode = pp_mode(h);
+                    // the GELU forms can defer their GELU step into the next tile's R segments (see PP_DEFER) when a tile has enough of them;
+                    // off by default: 833 against 686 us on the MAE decoder's lin1, 962 against 825 us on its gelu' GEMM (tools/bench_pp.py)
+                    static const bool env_defer = getenv("ACAI_GEMM_PP_DEFER") && atoi(getenv("ACAI_GEMM_PP_DEFER")) != 0;   // A/B aid
+                    if ((defer || env_defer) && g.K / BKG >= 8 && (mode == (PP_OBF | PP_GELU | PP_AUX1) || mode == (PP_OBF | PP_AUX2))) mode |= PP_DEFER;
+                    switch (mode) {
 #define PP_CASE(M) case (M): hipLaunchKernelGGL((gemm_nt_pp_kernel<T, (M)>), grid, block, 0, st, h); break
+                        PP_CASE(PP_OBF | PP_GELU | PP_AUX1 | PP_DEFER);
+                        PP_CASE(PP_OBF | PP_AUX2 | PP_DEFER);
                         PP_CASE(PP_OBF);
                         PP_CASE(PP_OBF | PP_SCALE);
                         PP_CASE(PP_OBF | PP_GELU | PP_AUX1);
@@ -2076,7 +2232,7 @@ int launch(const GemmArgs &g, hipStream_t st) {
 }  // namespace
 
 extern "C" int acai_gemm_set_variant(int variant) {
-    ACAI_CHECK_ARG(variant >= 0 && variant <= 7, "acai_gemm_set_variant: 0 (auto) .. 7");
+    ACAI_CHECK_ARG(variant >= 0 && variant <= 8, "acai_gemm_set_variant: 0 (auto) .. 8");
     g_gemm_variant = variant;
     return 0;
 }

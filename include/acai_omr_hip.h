@@ -54,7 +54,8 @@ int acai_gemm_nt_ex(const void *A, int lda, const void *W, int ldw, const float 
                     void *C, int ldc, void *aux, int ldaux, int aux_mode, int M, int N, int K, int in_dtype, int out_dtype, int flags,
                     int scale_cols, float col_scale, void *stream);
 /* Testing / tuning aid: pin the row-major GEMM kernel (0 auto; 1 128x128 two-stage; 2 256x128 two-stage; 3 256x128 three-stage; 4 256x128
- * persistent three-stage ring; 5 256x256 two-stage).  A pinned variant still falls back when the shape cannot use it.  No reference counterpart. */
+ * persistent three-stage ring; 5 256x256 two-stage; 6 persistent 256x256 ring of half-stages; 7 ping-pong wave groups with the register
+ * epilogue; 8 = 7 with the GELU forms' deferred epilogue).  A pinned variant still falls back when the shape cannot use it.  No reference counterpart. */
 int acai_gemm_set_variant(int variant);
 
 /* The same contraction with either operand stored reduction-major, for the backward of nn.Linear (autograd of M:29,57,...):

@@ -157,11 +157,14 @@ def test_attn_varlen_prescaled_needs_aligned_heads(dev):
 
 @pytest.mark.parametrize("prescaled", [False, True])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_attn_varlen_reference_maximum_restart(dev, dtype, prescaled):
+@pytest.mark.parametrize("causal,lens", [(False, [320, 200]), (True, [320, 200]), (False, [513, 200]), (True, [513, 130])])
+def test_attn_varlen_reference_maximum_restart(dev, dtype, prescaled, causal, lens):
     """The tiles in front of the ragged end take their reference maximum from tile 0 alone.  Scores that later rise past it by more than
-    2^80 (here: by ~130 in the log2 domain) overflow the row sum; the workgroup then starts over with a running maximum - same result."""
+    2^80 (here: by ~130 in the log2 domain) overflow the row sum; the workgroup then starts over with a running maximum - same result.
+    Causal and not, and with 513 queries (the fifth 128-query block holds one row: three of its waves are inactive and must keep the restarting
+    waves' barrier count)."""
     from acai_omr_amd import engine, ops
-    H, dh, lens = 2, 32, [320, 200]
+    H, dh = 2, 32
     E = H * dh
     g = torch.Generator().manual_seed(11)
     q = torch.randn(sum(lens), E, generator=g) * 0.1 + 4.0
@@ -169,15 +172,15 @@ def test_attn_varlen_reference_maximum_restart(dev, dtype, prescaled):
     v = torch.randn(sum(lens), E, generator=g)
     k[200] = 4.0          # sequence 0: one key 130 above everything before it, three tiles in
     k[250, :dh] = -4.0    # and a very negative one for head 0
-    k[320 + 150] = 3.0    # sequence 1
+    k[lens[0] + 100] = 3.0    # sequence 1
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
     q, k, v = (t.to(tdt).float() for t in (q, k, v))
     qd = (q * ops.QSCALE(dh)).to(tdt) if prescaled else q.to(tdt)
     q_ref = qd.double() / ops.QSCALE(dh) if prescaled else q
     cu = engine.cu_from_lens(lens, dev)
     lse = torch.empty(H * sum(lens), device=dev)
-    out = ops.attn_varlen(qd.to(dev), k.to(dev).to(tdt), v.to(dev).to(tdt), cu, cu, H, dh, max(lens), lse=lse, q_prescaled=prescaled)
-    ref = ref_attn(q_ref, k, v, lens, lens, H, dh, False)
+    out = ops.attn_varlen(qd.to(dev), k.to(dev).to(tdt), v.to(dev).to(tdt), cu, cu, H, dh, max(lens), causal=causal, lse=lse, q_prescaled=prescaled)
+    ref = ref_attn(q_ref, k, v, lens, lens, H, dh, causal)
     assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(lse).all())
     err = (out.cpu().double() - ref).abs().max()
     assert err < (2e-5 if dtype == "fp32" else 1.2e-2 * max(1.0, float(ref.abs().max()))), err
@@ -398,6 +401,36 @@ def test_gemm_nt_pingpong_epilogues(dev, K, shape):
             tol = 2.0 ** -7 * (y.abs() + 4.0) if ("res" in k) else 1e-5 * (y.abs() + 1.0) * K ** 0.5
             assert bool((d <= tol).all()), (k, float(d.max()))
             assert float((d > 1e-5 * (y.abs() + 1.0) * K ** 0.5).float().mean()) < 0.01, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(16384 + 8, 512, 512), (70000, 768, 512), (8192 + 40, 3072 + 24, 768)])
+def test_gemm_nt_pingpong_deferred_gelu(dev, shape):
+    """Variant 8: the ping-pong ring with the GELU forms' deferred epilogue (PP_DEFER - the tile boundary stores the bf16 linear output, the
+    GELU / gelu' step runs in 16-byte chunks beside the next tile's K-steps and the last tile's chunks after the loop).  Off by default (it
+    measured slower), kept runnable: it rounds at the same places as the undeferred form, so the two agree bit for bit."""
+    from acai_omr_amd import _lib, ops
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    bf = torch.bfloat16
+    a = torch.randn(M, K, generator=g).to(dev).to(bf)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev).to(bf)
+    b = torch.randn(N, generator=g).to(dev)
+    saved = torch.randn(M, N, generator=g).to(dev).to(bf)
+
+    def run(variant):
+        _lib.check(_lib.lib().acai_gemm_set_variant(variant), "acai_gemm_set_variant")
+        try:
+            pre = torch.empty(M, N, dtype=bf, device=dev)
+            y = ops.gemm_nt(a, w, b, out_dtype=bf, gelu=True, round_bf16=True, pre_act=pre)
+            dy = ops.gemm_nt(a, w, out_dtype=bf, round_bf16=True, gelu_grad_of=saved)
+            torch.cuda.synchronize()
+            return y, pre, dy
+        finally:
+            _lib.lib().acai_gemm_set_variant(0)
+
+    for x, y in zip(run(8), run(7)):
+        assert torch.equal(x, y)
 
 
 @pytest.mark.gpu
