@@ -294,8 +294,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
             __syncthreads();
         }
     } else {
-    for (int kt = 0; kt < n_fast; ++kt) {
-        const unsigned char *ldsK = smem + (kt & 1) * STAGE, *ldsV = ldsK + TT * RP;
+    // (the LDS stages are compile-time offsets - the loop is unrolled by two: chosen by `kt & 1`, every swizzled fragment address cost a VALU add
+    // per tile on top of its lane offset, 9-22 instructions per tile on a loop bound by the issue port)
+    auto fast_tile = [&](int kt, const unsigned char *cur, unsigned char *nxt) {
+        const unsigned char *ldsK = cur, *ldsV = cur + TT * RP;
         if (kt + 1 < nkt) stg.load(kt + 1, lk);
         f32x16 s0 = sinit, p0 = pinit, s1 = sinit, p1 = pinit;
         mma_rows2<T, DHP, NS>(s0, ldsK, qf, p0, ldsV, dof, 0, lr, lh);    // S^T[key][q] and dP^T[key][q] (- delta)
@@ -312,8 +314,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         for (int e = 0; e < 16; ++e) s1[e] = (PRE ? fast_exp2(s1[e]) : fast_exp2(fmaf(s1[e], c, -lse))) * (p1[e] - dsub);
 #pragma unroll
         for (int d = 0; d < NDB; ++d) mma_acc<T, DHP>(dqacc[d], ldsK, 32, d * 32, lane, s1);
-        if (kt + 1 < nkt) stg.store(smem + ((kt + 1) & 1) * STAGE);
+        if (kt + 1 < nkt) stg.store(nxt);
         __syncthreads();
+    };
+    {
+        int kt = 0;
+        for (; kt + 1 < n_fast; kt += 2) {
+            fast_tile(kt, smem, smem + STAGE);
+            fast_tile(kt + 1, smem + STAGE, smem);
+        }
+        if (kt < n_fast) fast_tile(kt, smem, smem + STAGE);
     }
     // ---- general loop: ragged last tile, causal tiles ------------------------------------------------------------------------------------
     for (int kt = n_fast; kt < nkt; ++kt) {
@@ -510,8 +520,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) 
     // d_h = 32; three waves per SIMD with one block at a time measured faster - tools/ab_attn.sh)
     const int n_fast = (!a.causal && k0 + OB <= lk) ? lq / TT : 0;
     constexpr bool STRAIGHT = ACAI_DKV_STRAIGHT && !(ES == 2 && DHP == 64);
-    for (int qt = qt0; qt < n_fast; ++qt) {
-        const unsigned char *cur = smem + ((qt - qt0) & 1) * STAGE;
+    // (n_fast > 0 only without the causal mask, i.e. qt0 = 0: tile qt sits in stage qt & 1.  The stages are compile-time offsets, the loop
+    // unrolled by two - see attn_bwd_dq_kernel)
+    auto fast_tile = [&](int qt, const unsigned char *cur, unsigned char *nxt) {
         if (qt + 1 < nqt) {
             stg.load(qt + 1, lq);
             load_stats(qt + 1);
@@ -532,7 +543,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) 
                 ds_dkv(cur, qt, qb, sacc, dpacc, nlse4, ndl4, true);
             }
         }
-        advance(qt);
+        if (qt + 1 < nqt) {
+            stg.store(nxt);
+            store_stats(nxt);
+        }
+        __syncthreads();
+    };
+    if constexpr (ES == 2 && DHP == 64) {
+        // (bf16 d_h = 64 holds 256 registers: unrolled, the allocator spilt and the backward measured 0-2 % slower - it keeps the rolled loop)
+        for (int qt = 0; qt < n_fast; ++qt) fast_tile(qt, smem + (qt & 1) * STAGE, smem + ((qt + 1) & 1) * STAGE);
+    } else {
+        int qt = 0;
+        for (; qt + 1 < n_fast; qt += 2) {
+            fast_tile(qt, smem, smem + STAGE);
+            fast_tile(qt + 1, smem + STAGE, smem);
+        }
+        if (qt < n_fast) fast_tile(qt, smem, smem + STAGE);
     }
     // ---- general loop: ragged tiles, causal tiles -----------------------------------------------------------------------------------------
     for (int qt = max(qt0, n_fast); qt < nqt; ++qt) {

@@ -25,6 +25,9 @@
 #ifndef ACAI_ATTN_PSUM4
 #define ACAI_ATTN_PSUM4 1
 #endif
+#ifndef ACAI_ATTN_MFMA_SUM
+#define ACAI_ATTN_MFMA_SUM 1
+#endif
 
 namespace {
 
@@ -179,7 +182,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WA
     };
     // O^T += V^T . P^T with P taken straight from the score accumulators (dropout, if any, masks the P that multiplies V only: the
     // normaliser uses the undropped probabilities)
-    auto pv = [&](f32x16 (&sacc)[2], const unsigned char *ldsV, int kt) {
+    // MFSUM (bf16, no dropout, fast loop): the row sums leave the VALU.  The packed P fragment of 16 keys, read as the B operand of a 16x16x32
+    // MFMA, is [k-group g = lane >> 4][n = lane & 15] with g = 0 / 2 the two key halves of query n and g = 1 / 3 those of query n + 16; against
+    // an A operand of ones in the k-groups {0, 2} for rows 0..7 and {1, 3} for rows 8..15 the product's rows 0..7 are the 16-key sum of query n
+    // and rows 8..15 that of query n + 16 - four 16-cycle MFMAs (8 issue cycles each) per tile on two alternating accumulators instead of 17
+    // v_pk_add_f32 behind the tile's last MFMA.  The sums are those of the bf16-ROUNDED probabilities, i.e. of exactly what multiplies V.
+    constexpr bool MFSUM = ACAI_ATTN_MFMA_SUM && ES == 2 && !DROP;
+    f32x4 lsum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const uint32_t selw = (((lane >> 4) & 1) == ((lane >> 3) & 1)) ? 0x3F803F80u : 0u;
+    const uint4 sel = make_uint4(selw, selw, selw, selw);
+    auto pv = [&](f32x16 (&sacc)[2], const unsigned char *ldsV, int kt, bool sum = false) {
         if constexpr (DROP) {
             const uint32_t rrow = (uint32_t)(h * a.total_q + q_start + my_q);
 #pragma unroll
@@ -200,6 +212,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WA
                     pf.y = pack_bf16(sacc[kb][8 * s2 + 2], sacc[kb][8 * s2 + 3]);
                     pf.z = pack_bf16(sacc[kb][8 * s2 + 4], sacc[kb][8 * s2 + 5]);
                     pf.w = pack_bf16(sacc[kb][8 * s2 + 6], sacc[kb][8 * s2 + 7]);
+                    if constexpr (MFSUM) {
+                        if (sum) lsum[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, sel), __builtin_bit_cast(bf16x8, pf), lsum[s2], 0, 0, 0);
+                    }
 #pragma unroll
                     for (int d = 0; d < NDB; ++d) {
                         // A element j = V[key 16 s2 + 8 (j>>2) + 4 lh + (j&3)][d]: two 4-key x 16-d transposing reads of the natural V tile
@@ -278,32 +293,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WA
             }
             __syncthreads();
         }
-    } else
-    for (int kt = 0; kt < n_fast; ++kt) {
-        const unsigned char *ldsK = lds + (kt & 1) * STAGE, *ldsV = ldsK + KT * KPITCH;
-        if (kt + 1 < nkt) load_tile(kt + 1);
-        f32x16 sacc[2] = {minit, minit};
-        qk(sacc, ldsK);
+    } else {
+        // One tile of the fast loop.  `cur` / `nxt` are the LDS stages as COMPILE-TIME offsets (the loop below is unrolled by two): with the
+        // stage chosen by `kt & 1` every swizzled fragment address cost a v_add / v_or per tile on top of its lane offset - 14 VALU instructions
+        // per tile at d_h = 32 and 27 at d_h = 64 on a loop that is bound by the issue port; as constants they fold into the reads' offset fields.
+        auto fast_tile = [&](int kt, const unsigned char *cur, unsigned char *nxt) {
+            const unsigned char *ldsK = cur, *ldsV = cur + KT * KPITCH;
+            if (kt + 1 < nkt) load_tile(kt + 1);
+            f32x16 sacc[2] = {minit, minit};
+            qk(sacc, ldsK);
 #if ACAI_ATTN_QK_FIRST
-        __builtin_amdgcn_sched_barrier(0);   // all four S^T MFMAs first: the second key block's run under the first block's exponentials
+            __builtin_amdgcn_sched_barrier(0);   // all four S^T MFMAs first: the second key block's run under the first block's exponentials
 #endif
-        // four independent partial sums: one running sum made a chain of 32 dependent v_add_f32 per tile (a dependent add issues every
-        // ~6.6 cycles instead of 4: +80 cycles per tile on a loop whose floor is ~520)
-        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+            // four independent partial sums: one running sum made a chain of 32 dependent v_add_f32 per tile (a dependent add issues every
+            // ~6.6 cycles instead of 4: +80 cycles per tile on a loop whose floor is ~520)
+            float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float p = PRE ? fast_exp2(sacc[kb][e]) : fast_exp2(fmaf(sacc[kb][e], c, -m_run));
-                sacc[kb][e] = p;
-                ps[ACAI_ATTN_PSUM4 ? (e & 3) : 0] += p;
+                for (int e = 0; e < 16; ++e) {
+                    const float p = PRE ? fast_exp2(sacc[kb][e]) : fast_exp2(fmaf(sacc[kb][e], c, -m_run));
+                    sacc[kb][e] = p;
+                    if constexpr (!MFSUM) ps[ACAI_ATTN_PSUM4 ? (e & 3) : 0] += p;
+                }
+            if constexpr (!MFSUM) {
+                const float psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+                bad |= !(psum < 1.2e24f);   // 2^80; also true for inf and NaN
+                l_run += psum;
             }
-        const float psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
-        bad |= !(psum < 1.2e24f);   // 2^80; also true for inf and NaN
-        l_run += psum;
-        pv(sacc, ldsV, kt);
-        if (kt + 1 < nkt) store_tile(lds + ((kt + 1) & 1) * STAGE);
-        __syncthreads();   // one barrier per tile: stage (kt+1)&1 was last read in iteration kt-1
+            pv(sacc, ldsV, kt, true);
+            if (kt + 1 < nkt) store_tile(nxt);
+            __syncthreads();   // one barrier per tile: the other stage was last read in iteration kt-1
+        };
+        int kt = 0;
+        for (; kt + 1 < n_fast; kt += 2) {
+            fast_tile(kt, lds, lds + STAGE);
+            fast_tile(kt + 1, lds + STAGE, lds);
+        }
+        if (kt < n_fast) fast_tile(kt, lds, lds + STAGE);
+    }
+    if constexpr (MFSUM) {
+        // rows 0..7 (any register of lanes 0..31) hold the sum of query n = lane & 15, rows 8..15 (lanes 32..63) that of query n + 16; l_run is
+        // a per-lane-half partial sum (the halves meet after the loops), so the whole sum goes to the lower half.  One check for the whole
+        // loop: a probability beyond 2^100 (or inf / NaN) shows in its row's sum
+        const float full = __shfl(lsum[0][0] + lsum[1][0], (lane & 16) ? 32 + (lane & 15) : (lane & 15));
+        if (wave_active && n_fast > 0) {
+            bad = !(full < 1.2e30f);
+            l_run = lh == 0 ? full : 0.f;
+        }
     }
     int kt0 = n_fast;
     if (n_fast > 0 && __syncthreads_or(bad)) {   // start over with a running maximum (all waves: the barrier count must match)
