@@ -18,12 +18,14 @@ def t(fn, iters=10):
 
 
 rows = []
-def fwd(name, M, N, K, count, resid=False, gelu=False, out32=False):
+def fwd(name, M, N, K, count, resid=False, gelu=False, out32=False, dgelu=False, scale=False):
     a = torch.randn(M, K, device=dev).to(bf); w = torch.randn(N, K, device=dev).to(bf); b = torch.randn(N, device=dev)
     r = torch.randn(M, N, device=dev) if resid else None
     out = torch.empty(M, N, device=dev, dtype=torch.float32 if (resid or out32) else bf)
     pre = torch.empty(M, N, device=dev, dtype=bf) if gelu else None
-    s = t(lambda: ops.gemm_nt(a, w, b, residual=r, out=out, gelu=gelu, round_bf16=True, pre_act=pre))
+    saved = torch.randn(M, N, device=dev).to(bf) if dgelu else None      # the kept pre-activation whose GELU derivative multiplies the product
+    s = t(lambda: ops.gemm_nt(a, w, None if dgelu else b, residual=r, out=out, gelu=gelu, round_bf16=True, pre_act=pre, gelu_grad_of=saved,
+                              col_scale=(N // 3, 0.18) if scale else None))
     rows.append((name, M, N, K, count, s))
 
 def dw(name, M, N, K, count):   # dW[N, K] = dY[M, N]^T X[M, K]
@@ -33,13 +35,13 @@ def dw(name, M, N, K, count):   # dW[N, K] = dY[M, N]^T X[M, K]
 
 Me, Md = 32768, 131072
 for tag, M, d, L in (("enc", Me, 768, 12), ("dec", Md, 512, 8)):
-    fwd(f"{tag} qkv fwd", M, 3 * d, d, L)
+    fwd(f"{tag} qkv fwd (q scale)", M, 3 * d, d, L, scale=True)
     fwd(f"{tag} out fwd (+res)", M, d, d, L, resid=True)
     fwd(f"{tag} lin1 fwd (gelu)", M, 3072, d, L, gelu=True)
     fwd(f"{tag} lin2 fwd (+res)", M, d, 3072, L, resid=True)
     fwd(f"{tag} dattn = dy Wo", M, d, d, L)
     fwd(f"{tag} dx = dqkv Wi (+res)", M, d, 3 * d, L, resid=True)
-    fwd(f"{tag} da = dy W2 (gelu')", M, 3072, d, L)
+    fwd(f"{tag} da = dy W2 (gelu')", M, 3072, d, L, dgelu=True)
     fwd(f"{tag} dx = da W1 (+res)", M, d, 3072, L, resid=True)
     dw(f"{tag} dWi", M, 3 * d, d, L)
     dw(f"{tag} dWo", M, d, d, L)
