@@ -29,6 +29,11 @@ class AcaiAdamWTensor(Structure):
                 ("bias_c1", c_float), ("bias_c2_sqrt", c_float)]
 
 
+class AcaiCastEntry(Structure):
+    _fields_ = [("src", c_void_p), ("dst16", c_void_p), ("dst16t", c_void_p), ("dst32r", c_void_p), ("rows", c_int32), ("cols", c_int32),
+                ("tile0", c_int32), ("pad_", c_int32)]
+
+
 class AcaiAdamWGroup(Structure):
     _fields_ = [(n, c_float) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "pad0_", "pad1_", "pad2_")]
 
@@ -69,6 +74,7 @@ _SIGNATURES = {
     "acai_gelu_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "acai_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "acai_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "acai_cast_weights": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "acai_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "acai_scatter_add_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "acai_mae_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),

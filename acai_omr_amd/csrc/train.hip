@@ -530,3 +530,92 @@ extern "C" int acai_adamw_step(const AcaiAdamWTensor *tensors, const AcaiAdamWGr
     ACAI_LAUNCH_CHECK("acai_adamw_step");
     return 0;
 }
+
+// ---- operand copies of the fp32 master weights, all tensors in ONE launch -----------------------------------------------------------------
+// After an optimizer step every cached bf16 operand copy of every parameter is stale (engine.WeightCache: autocast's weight cast done once
+// per parameter version): the bf16 copy [rows][cols] (forward operand), the TRANSPOSED bf16 copy [cols][rows] (dX = dY . W as a row-major
+// GEMM) and, for biases, the bf16-rounded fp32 vector.  Through ATen that was one cast / copy launch per tensor and kind (~300 launches of
+// ~5-13 us per MAE step, ~2 ms).  Here: a table of entries, 64 x 64 tiles, the transposition through LDS.  HBM-bound, ~1 GB per step.
+namespace {
+__global__ __launch_bounds__(256) void cast_weights_kernel(const AcaiCastEntry *__restrict__ table, int n_entries) {
+    __shared__ uint16_t tl[64][66];
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    int lo = 0, hi = n_entries - 1;   // last entry with tile0 <= tile
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].tile0 <= tile) lo = mid; else hi = mid - 1;
+    }
+    const AcaiCastEntry e = table[lo];
+    const int tiles_c = (e.cols + 63) >> 6, lt = tile - e.tile0;
+    const int r0 = (lt / tiles_c) * 64, c0 = (lt % tiles_c) * 64;
+    const int ty = tid >> 4, tx = tid & 15;
+    const bool vec = (e.cols & 3) == 0;
+    bf16_t *d16 = reinterpret_cast<bf16_t *>(e.dst16), *d16t = reinterpret_cast<bf16_t *>(e.dst16t);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 16 * i, c = c0 + tx * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < e.rows) {
+            const float *sp = e.src + (size_t)r * e.cols + c;
+            if (vec && c < e.cols) {
+                const f32x4 q = *reinterpret_cast<const f32x4 *>(sp);
+                v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < e.cols) v[j] = sp[j];
+            }
+            bf16_t b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = f2bf(v[j]);
+            if (d16) {
+                bf16_t *dp = d16 + (size_t)r * e.cols + c;
+                if (vec && c < e.cols) {
+                    uint2 o;
+                    o.x = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
+                    o.y = (uint32_t)b[2] | ((uint32_t)b[3] << 16);
+                    *reinterpret_cast<uint2 *>(dp) = o;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (c + j < e.cols) dp[j] = b[j];
+                }
+            }
+            if (e.dst32r) {
+                float *dp = e.dst32r + (size_t)r * e.cols + c;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < e.cols) dp[j] = bf2f(b[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tl[ty + 16 * i][tx * 4 + j] = b[j];
+        }
+    }
+    if (!d16t) return;   // (entry-uniform: the whole workgroup leaves)
+    __syncthreads();
+    const bool vect = (e.rows & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cl = ty + 16 * i, c = c0 + cl, r = r0 + tx * 4;   // output row c, output columns r .. r+3
+        if (c >= e.cols || r >= e.rows) continue;
+        bf16_t *dp = d16t + (size_t)c * e.rows + r;
+        if (vect) {
+            uint2 o;
+            o.x = (uint32_t)tl[tx * 4 + 0][cl] | ((uint32_t)tl[tx * 4 + 1][cl] << 16);
+            o.y = (uint32_t)tl[tx * 4 + 2][cl] | ((uint32_t)tl[tx * 4 + 3][cl] << 16);
+            *reinterpret_cast<uint2 *>(dp) = o;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (r + j < e.rows) dp[j] = tl[tx * 4 + j][cl];
+        }
+    }
+}
+}  // namespace
+
+extern "C" int acai_cast_weights(const AcaiCastEntry *table, int n_entries, int n_tiles, void *stream) {
+    ACAI_CHECK_ARG(table && n_entries > 0 && n_tiles > 0, "acai_cast_weights: bad arguments");
+    hipLaunchKernelGGL(cast_weights_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, table, n_entries);
+    ACAI_LAUNCH_CHECK("acai_cast_weights");
+    return 0;
+}

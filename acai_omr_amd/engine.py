@@ -13,6 +13,8 @@ torch.autocast(bfloat16) does to linear / SDPA (bf16 operands and outputs, fp32 
 import ctypes
 import os
 
+import weakref
+
 import torch
 
 from . import _lib, ops
@@ -41,11 +43,42 @@ class WeightCache:
         key = (id(p), kind)
         tag = (p._version, p.data_ptr())
         hit = self._c.get(key)
+        if hit is not None and hit[0] != tag and kind in self._BATCHED and p.is_cuda and not torch.cuda.is_current_stream_capturing():
+            self._refresh_stale(p.device)      # an optimizer step went by: every stale copy on this device in ONE launch
+            hit = self._c.get(key)
         if hit is None or hit[0] != tag:
             with torch.no_grad():
-                hit = (tag, make(p.detach()))
+                hit = (tag, make(p.detach()), weakref.ref(p))
             self._c[key] = hit
         return hit[1]
+
+    _BATCHED = ("w16", "wtbf16", "b16")
+
+    def _refresh_stale(self, device):
+        """Rebuild every cached bf16 / transposed-bf16 / rounded-bias copy whose parameter moved on (version or storage) with one
+        `acai_cast_weights` launch (through ATen: one cast or copy launch per tensor and kind, ~300 per training step).  Fresh output tensors:
+        a copy still referenced by an autograd graph keeps its old values."""
+        groups = {}
+        for (pid, kind), (tag, _, ref) in list(self._c.items()):
+            p = ref()
+            if p is None:
+                del self._c[(pid, kind)]
+                continue
+            if kind not in self._BATCHED or p.device != device or tag == (p._version, p.data_ptr()):
+                continue
+            if p.dtype != torch.float32 or not p.is_contiguous() or p.dim() != (1 if kind == "b16" else 2):
+                continue
+            groups.setdefault(pid, (p, set()))[1].add(kind)
+        if not groups:
+            return
+        order = list(groups.values())
+        with torch.no_grad():
+            outs = ops.cast_weights([(p.detach(), "w16" in ks, "wtbf16" in ks, "b16" in ks) for p, ks in order])
+        for (p, ks), (d16, d16t, d32) in zip(order, outs):
+            tag = (p._version, p.data_ptr())
+            for kind, t in (("w16", d16), ("wtbf16", d16t), ("b16", d32)):
+                if kind in ks:
+                    self._c[(id(p), kind)] = (tag, t, weakref.ref(p))
 
     def w(self, p, prec):
         if prec == "fp32":

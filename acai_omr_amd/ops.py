@@ -367,7 +367,7 @@ def layernorm_bwd(x, w, dy, eps, want_param_grads=True, want_bf16=False, want_co
     dxb = torch.empty(rows, dim, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
     stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
     n_acc = (2 if want_param_grads else 0) + (1 if want_colsum else 0)
-    acc = torch.zeros(max(n_acc, 1), dim, dtype=torch.float32, device=x.device)   # one fill for every accumulated vector
+    acc = _ZEROS.take(max(n_acc, 1), dim, x.device)   # zeroed accumulators: slices of the arena's chunk (one fill per 256 MB, not one per call)
     dw = acc[0] if want_param_grads else None
     db = acc[1] if want_param_grads else None
     dcs = acc[n_acc - 1] if want_colsum else None
@@ -375,6 +375,32 @@ def layernorm_bwd(x, w, dy, eps, want_param_grads=True, want_bf16=False, want_co
                                              stats.data_ptr(), rows, dim, _st()), "acai_layernorm_bwd")
     out = (dx, dw, db, dxb) if want_bf16 else (dx, dw, db)
     return out + (dcs,) if want_colsum else out
+
+
+def cast_weights(items):
+    """One launch for the operand copies of many fp32 parameters (engine.WeightCache after an optimizer step).  items: (src, want16, want16t,
+    want32r) with src a contiguous fp32 CUDA tensor of one or two dimensions; returns per item (bf16 copy | None, transposed bf16 copy
+    [cols, rows] | None, bf16-rounded fp32 copy | None).  Replaces `t.to(bfloat16)`, `out.copy_(t.t())` and `t.to(bfloat16).to(float32)`."""
+    if not items:
+        return []
+    dev = items[0][0].device
+    arr = (_lib.AcaiCastEntry * len(items))()
+    outs, tiles = [], 0
+    for i, (src, w16, w16t, w32r) in enumerate(items):
+        _chk(src, "src", torch.float32)
+        assert src.is_contiguous() and src.dim() in (1, 2) and src.device == dev
+        rows, cols = (1, src.shape[0]) if src.dim() == 1 else src.shape
+        d16 = torch.empty(src.shape, dtype=torch.bfloat16, device=dev) if w16 else None
+        d16t = torch.empty((cols, rows), dtype=torch.bfloat16, device=dev) if w16t else None
+        d32 = torch.empty(src.shape, dtype=torch.float32, device=dev) if w32r else None
+        arr[i].src, arr[i].dst16, arr[i].dst16t, arr[i].dst32r = src.data_ptr(), _p(d16), _p(d16t), _p(d32)
+        arr[i].rows, arr[i].cols, arr[i].tile0 = rows, cols, tiles
+        tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
+        outs.append((d16, d16t, d32))
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().acai_cast_weights(table.data_ptr(), len(items), tiles, _st()), "acai_cast_weights")
+    return outs
 
 
 def gelu_fwd(a):
@@ -396,7 +422,7 @@ def gelu_bwd(a, dh):
 def colsum(x):
     _chk(x, "x")
     assert x.dim() == 2
-    out = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+    out = _ZEROS.take(1, x.shape[1], x.device).view(-1)
     _lib.check(_lib.lib().acai_colsum(x.data_ptr(), x.stride(0), out.data_ptr(), x.shape[0], x.shape[1], _dt(x), _st()), "acai_colsum")
     return out
 

@@ -182,6 +182,19 @@ typedef struct AcaiAdamWGroup {
 int acai_adamw_step(const AcaiAdamWTensor *tensors, const AcaiAdamWGroup *groups, const int32_t *chunk_tensor, const int64_t *chunk_off,
                     int n_chunks, int chunk_elems, float grad_scale, void *stream);
 
+/* The operand copies autocast makes of the fp32 master weights (torch casts each nn.Linear weight / bias to bf16 on every call under
+ * torch.autocast, omr_teacher_force_train.py:112-116; this path caches them per parameter version) for ALL parameters in one launch, after an
+ * optimizer step: per entry any of the bf16 copy [rows][cols], the transposed bf16 copy [cols][rows] (the dX GEMM's row-major operand) and
+ * the bf16-rounded fp32 copy (biases).  `table` is device memory; tile0 = running sum of ceil(rows/64) * ceil(cols/64) over the entries
+ * before this one, n_tiles the total.  src and the destinations are contiguous; destinations are 8-byte aligned. */
+typedef struct AcaiCastEntry {
+    const float *src;
+    void *dst16, *dst16t;
+    float *dst32r;
+    int32_t rows, cols, tile0, pad_;
+} AcaiCastEntry;
+int acai_cast_weights(const AcaiCastEntry *table, int n_entries, int n_tiles, void *stream);
+
 /* ---- KV-cached greedy decode (K:190-223, K:292-302, M:518-528, M:575-583) ------------------------------- */
 typedef struct {
     const void *self_in_w;   const float *self_in_b;   /* self_attn.in_proj_{weight,bias} [3E,E] */

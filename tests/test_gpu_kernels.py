@@ -450,3 +450,60 @@ def test_gemm_weight_gradient_pingpong(dev, shape):
     # accumulation into an existing gradient (the arena hands out zeroed views; a second product adds on top)
     out2 = ops.gemm(dy.to(dev), x.to(dev), trans_a=True, trans_w=True, out=out)
     assert (out2.cpu().double() - 2 * ref).abs().max() < 4e-3 * float(ref.abs().max()) + 2e-4
+
+
+@pytest.mark.gpu
+def test_cast_weights_one_launch_equals_aten(dev):
+    """acai_cast_weights: the bf16 copy, the transposed bf16 copy and the bf16-rounded fp32 copy of many fp32 tensors in one launch are bit for
+    bit what ATen's casts / transposing copy give (ragged and odd shapes, vectors, NaN / inf / denormals kept)."""
+    from acai_omr_amd import ops
+    g = torch.Generator().manual_seed(5)
+    shapes = [(3072, 512), (227, 1024), (512, 3072), (65, 130), (5, 3), (1, 7), (3072,), (227,), (1,), (64, 64), (130, 4)]
+    srcs = [torch.randn(*s, generator=g).to(dev) for s in shapes]
+    srcs[3][0, :5] = torch.tensor([float("nan"), float("inf"), -float("inf"), 1e-40, -0.0], device=dev)
+    items = []
+    for i, t in enumerate(srcs):
+        two = t.dim() == 2
+        items.append((t, two or i % 2 == 0, two, (not two) or i % 3 == 0))
+    outs = ops.cast_weights(items)
+    torch.cuda.synchronize()
+    for (t, w16, w16t, w32), (d16, d16t, d32) in zip(items, outs):
+        ref = t.to(torch.bfloat16)
+        same = lambda a, b: torch.equal(a.view(torch.int16), b.view(torch.int16))
+        assert (d16 is not None) == bool(w16) and (d16t is not None) == bool(w16t) and (d32 is not None) == bool(w32)
+        if w16:
+            assert d16.shape == t.shape and same(d16, ref)
+        if w16t:
+            assert d16t.shape == (t.shape[1], t.shape[0]) and d16t.is_contiguous() and same(d16t, ref.t().contiguous())
+        if w32:
+            assert d32.dtype == torch.float32 and torch.equal(d32.view(torch.int32), ref.float().view(torch.int32))
+
+
+@pytest.mark.gpu
+def test_weight_cache_refreshes_all_stale_copies_together(dev):
+    """engine.WeightCache after an optimizer-style in-place update: the first request refreshes every stale copy in one launch; values equal
+    fresh ATen casts, copies handed out before keep the old values (they may sit in an autograd graph), untouched parameters keep their copy."""
+    from acai_omr_amd import engine
+    torch.manual_seed(0)
+    lin = [torch.nn.Linear(96, 200).to(dev), torch.nn.Linear(200, 72).to(dev), torch.nn.Linear(8, 8).to(dev)]
+    wc = engine.WeightCache()
+    before = [(wc.w(l.weight, "bf16"), wc.wt(l.weight, "bf16"), wc.b(l.bias, "bf16")) for l in lin]
+    keep = [tuple(t.clone() for t in trip) for trip in before]
+    with torch.no_grad():
+        for l in lin[:2]:
+            l.weight.mul_(1.5)
+            l.bias.add_(0.25)
+    launches = []
+    orig = engine.ops.cast_weights
+    engine.ops.cast_weights = lambda items: (launches.append(len(items)), orig(items))[1]
+    try:
+        after = [(wc.w(l.weight, "bf16"), wc.wt(l.weight, "bf16"), wc.b(l.bias, "bf16")) for l in lin]
+    finally:
+        engine.ops.cast_weights = orig
+    assert launches == [4]                       # two weights (both kinds in one entry each) + two biases, one launch
+    for l, (w, wt, b) in zip(lin, after):
+        ref = l.weight.detach().to(torch.bfloat16)
+        assert torch.equal(w, ref) and torch.equal(wt, ref.t().contiguous()) and torch.equal(b, l.bias.detach().to(torch.bfloat16).float())
+    for old, kept in zip(before, keep):
+        assert all(torch.equal(a, b) for a, b in zip(old, kept))
+    assert all(a is b for a, b in zip(before[2], after[2]))      # the untouched layer's copies are the same tensors
