@@ -357,9 +357,10 @@ def dropout_add(x, residual, p, seed, out_dtype=None):
     return out
 
 
-def layernorm_bwd(x, w, dy, eps, want_param_grads=True, want_bf16=False, want_colsum=False):
+def layernorm_bwd(x, w, dy, eps, want_param_grads=True, want_bf16=False, want_colsum=False, accum_into=None):
     """Returns (dx, dw, db) or, with want_bf16 (dim % 256 == 0, dim <= 1024), (dx, dw, db, dx_bf16); want_colsum appends the column sums of
-    dx (of its bf16 copy when one is written): the bias gradient of the nn.Linear whose output this LayerNorm normalised."""
+    dx (of its bf16 copy when one is written): the bias gradient of the nn.Linear whose output this LayerNorm normalised.
+    accum_into = (dw, db): existing fp32 vectors the parameter gradients are ADDED to (returned dw / db are then None)."""
     _chk(x, "x", torch.float32), _chk(dy, "dy", torch.float32)
     assert x.is_contiguous() and dy.is_contiguous() and x.shape == dy.shape
     rows, dim = x.shape
@@ -371,8 +372,15 @@ def layernorm_bwd(x, w, dy, eps, want_param_grads=True, want_bf16=False, want_co
     dw = acc[0] if want_param_grads else None
     db = acc[1] if want_param_grads else None
     dcs = acc[n_acc - 1] if want_colsum else None
+    if accum_into is not None:
+        assert want_param_grads
+        dw, db = accum_into
+        _chk(dw, "dw", torch.float32), _chk(db, "db", torch.float32)
+        assert dw.is_contiguous() and db.is_contiguous() and dw.numel() == dim and db.numel() == dim
     _lib.check(_lib.lib().acai_layernorm_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), float(eps), dx.data_ptr(), _p(dxb), _p(dw), _p(db), _p(dcs),
                                              stats.data_ptr(), rows, dim, _st()), "acai_layernorm_bwd")
+    if accum_into is not None:
+        dw = db = None
     out = (dx, dw, db, dxb) if want_bf16 else (dx, dw, db)
     return out + (dcs,) if want_colsum else out
 
@@ -419,10 +427,15 @@ def gelu_bwd(a, dh):
     return da
 
 
-def colsum(x):
+def colsum(x, out=None):
+    """Column sums of x (fp32).  out: an existing fp32 vector to ADD them to (the kernel accumulates with float atomics)."""
     _chk(x, "x")
     assert x.dim() == 2
-    out = _ZEROS.take(1, x.shape[1], x.device).view(-1)
+    if out is None:
+        out = _ZEROS.take(1, x.shape[1], x.device).view(-1)
+    else:
+        _chk(out, "out", torch.float32)
+        assert out.is_contiguous() and out.numel() == x.shape[1]
     _lib.check(_lib.lib().acai_colsum(x.data_ptr(), x.stride(0), out.data_ptr(), x.shape[0], x.shape[1], _dt(x), _st()), "acai_colsum")
     return out
 

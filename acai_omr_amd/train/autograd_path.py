@@ -13,6 +13,8 @@ the inference path.  Dropout (train mode) is a counter-based hash mask regenerat
 """
 import os
 
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -86,6 +88,52 @@ def _side_take(t):
     return _side_take2(t)[0]
 
 
+# ---- parameters used more than once in a graph ---------------------------------------------------------------------------
+# Scheduled sampling runs the decoder twice, so every decoder parameter receives two gradient contributions in one backward pass, and autograd
+# sums them with one `add` launch per parameter (~270 six-microsecond launches per teacher-forced step).  The weight-gradient GEMM, the column
+# sums and the LayerNorm backward all ACCUMULATE into their (zeroed) outputs, so the second contribution goes straight into the first one's
+# tensor - which autograd is still holding for the parameter's accumulation node - and reports "no gradient".  Keyed on the engine's graph-task
+# id: a tensor of an earlier backward pass is never touched.  Weak references: nothing is kept alive.
+_PGRAD = {}
+PGRAD_FUSE = os.environ.get("ACAI_PGRAD_FUSE", "1") != "0"   # A/B and test aid
+
+
+def _pgrad_prev(param):
+    tid = torch._C._current_graph_task_id() if PGRAD_FUSE else -1
+    if tid < 0 or param is None or not param.is_leaf:     # (slices of a parameter are fresh objects per call: their ids mean nothing)
+        return None
+    hit = _PGRAD.get(id(param))
+    return hit[1]() if hit is not None and hit[0] == tid and hit[2]() is param else None
+
+
+def _pgrad_note(param, g):
+    tid = torch._C._current_graph_task_id()
+    if tid >= 0 and g is not None and param is not None and param.is_leaf:
+        _PGRAD[id(param)] = (tid, weakref.ref(g), weakref.ref(param))
+    return g
+
+
+def _wgrad(W, dy, x):
+    """dW = dy^T x (fp32, split-K atomics into a zeroed tensor)."""
+    prev = _pgrad_prev(W)
+    if prev is not None:
+        ops.gemm(dy, x, trans_a=True, trans_w=True, out=prev)
+        return None
+    return _pgrad_note(W, ops.gemm(dy, x, trans_a=True, trans_w=True, out_dtype=torch.float32))
+
+
+def _bgrad(b, dy, cs=None):
+    """db = column sums of dy (cs: already formed by the LayerNorm backward that produced dy)."""
+    prev = _pgrad_prev(b)
+    if prev is not None:
+        if cs is not None:
+            prev.add_(cs)
+        else:
+            ops.colsum(dy, out=prev)
+        return None
+    return _pgrad_note(b, cs if cs is not None else ops.colsum(dy))
+
+
 # ---- autograd Functions ---------------------------------------------------------------------------------------------------
 class LinearFn(Function):
     """y = x @ W^T + b (+ residual).  x in the compute dtype; y fp32 when a residual is added, else compute dtype (or fp32 on request)."""
@@ -98,20 +146,20 @@ class LinearFn(Function):
         Wc, bc = wc.w(W, prec), wc.b(b, prec)
         out_dtype = torch.float32 if (residual is not None or out_fp32 or not bf) else torch.bfloat16
         y = ops.gemm_nt(x, Wc, bc, residual=residual, out_dtype=out_dtype, round_bf16=bf, col_scale=col_scale)
-        ctx.save_for_backward(x, W)
+        ctx.save_for_backward(x, W, b)
         ctx.prec, ctx.wc, ctx.has_res, ctx.has_bias = prec, wc, residual is not None, b is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, W = ctx.saved_tensors
+        x, W, b = ctx.saved_tensors
         prec, bf = ctx.prec, ctx.prec == "bf16"
         dy = dy.contiguous()
         dres = dy if ctx.has_res else None
         dyc, cs = _grad_copy_cs(dy, prec)
         dx = ops.gemm_nt(dyc, ctx.wc.wt(W, prec), out_dtype=x.dtype) if ctx.needs_input_grad[0] else None
-        dW = ops.gemm(dyc, x, trans_a=True, trans_w=True, out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
-        db = (cs if cs is not None else ops.colsum(dyc)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dW = _wgrad(W, dyc, x) if ctx.needs_input_grad[1] else None
+        db = _bgrad(b, dyc, cs) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dW, db, dres, None, None, None, None
 
 
@@ -156,24 +204,24 @@ class MlpFn(Function):
         a = torch.empty(x.shape[0], W1.shape[0], dtype=cdt, device=x.device)
         h = ops.gemm_nt(x, wc.w(W1, prec), wc.b(b1, prec), out_dtype=cdt, gelu=True, round_bf16=bf, pre_act=a)
         y = ops.gemm_nt(h, wc.w(W2, prec), wc.b(b2, prec), residual=x32, out_dtype=torch.float32, round_bf16=bf)
-        ctx.save_for_backward(x, a, h, W1, W2)
+        ctx.save_for_backward(x, a, h, W1, W2, b1, b2)
         ctx.prec, ctx.wc = prec, wc
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, a, h, W1, W2 = ctx.saved_tensors
+        x, a, h, W1, W2, b1, b2 = ctx.saved_tensors
         prec, wc, bf = ctx.prec, ctx.wc, ctx.prec == "bf16"
         dy = dy.contiguous()
         dyc, cs = _grad_copy_cs(dy, prec)
         da = ops.gemm_nt(dyc, wc.wt(W2, prec), out_dtype=a.dtype, round_bf16=bf, gelu_grad_of=a)     # (dY . W2) o gelu'(a)
-        dW2 = ops.gemm(dyc, h, trans_a=True, trans_w=True, out_dtype=torch.float32) if ctx.needs_input_grad[3] else None
-        db2 = (cs if cs is not None else ops.colsum(dyc)) if ctx.needs_input_grad[4] else None
+        dW2 = _wgrad(W2, dyc, h) if ctx.needs_input_grad[3] else None
+        db2 = _bgrad(b2, dyc, cs) if ctx.needs_input_grad[4] else None
         dx = None
         if ctx.needs_input_grad[0]:   # branch gradient (rounded to the compute dtype as the unfused path does) + residual gradient, fp32
             dx = ops.gemm_nt(da, wc.wt(W1, prec), residual=dy.float() if dy.dtype != torch.float32 else dy, out_dtype=torch.float32, round_bf16=bf)
-        dW1 = ops.gemm(da, x, trans_a=True, trans_w=True, out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
-        db1 = ops.colsum(da) if ctx.needs_input_grad[2] else None
+        dW1 = _wgrad(W1, da, x) if ctx.needs_input_grad[1] else None
+        db1 = _bgrad(b1, da) if ctx.needs_input_grad[2] else None
         return dx, dW1, db1, dW2, db2, None, None
 
 
@@ -195,29 +243,29 @@ class SelfAttnBlockFn(Function):
         lse = torch.empty(H * x.shape[0], dtype=torch.float32, device=x.device)
         attn = ops.attn_varlen(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], cu, cu, H, dh, max_len, causal=causal, lse=lse, q_prescaled=pre)
         y = ops.gemm_nt(attn, wc.w(Wo, prec), wc.b(bo, prec), residual=x32, out_dtype=torch.float32, round_bf16=bf)
-        ctx.save_for_backward(x, qkv, attn, lse, cu, Wi, Wo)
+        ctx.save_for_backward(x, qkv, attn, lse, cu, Wi, Wo, bi, bo)
         ctx.cfg = (H, dh, max_len, causal, prec, wc, pre)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, qkv, attn, lse, cu, Wi, Wo = ctx.saved_tensors
+        x, qkv, attn, lse, cu, Wi, Wo, bi, bo = ctx.saved_tensors
         H, dh, max_len, causal, prec, wc, pre = ctx.cfg
         bf = prec == "bf16"
         E = H * dh
         dy = dy.contiguous()
         dyc, cs = _grad_copy_cs(dy, prec)
         dattn = ops.gemm_nt(dyc, wc.wt(Wo, prec), out_dtype=attn.dtype, round_bf16=bf)
-        dWo = ops.gemm(dyc, attn, trans_a=True, trans_w=True, out_dtype=torch.float32) if ctx.needs_input_grad[3] else None
-        dbo = (cs if cs is not None else ops.colsum(dyc)) if ctx.needs_input_grad[4] else None
+        dWo = _wgrad(Wo, dyc, attn) if ctx.needs_input_grad[3] else None
+        dbo = _bgrad(bo, dyc, cs) if ctx.needs_input_grad[4] else None
         dqkv = torch.empty_like(qkv)
         ops.attn_varlen_bwd(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], attn, dattn, lse, cu, cu, H, dh, max_len, max_len, causal,
                             dqkv[:, :E], dqkv[:, E:2 * E], dqkv[:, 2 * E:], q_prescaled=pre)   # dq: w.r.t. the UNSCALED in-projection output
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_nt(dqkv, wc.wt(Wi, prec), residual=dy.float() if dy.dtype != torch.float32 else dy, out_dtype=torch.float32, round_bf16=bf)
-        dWi = ops.gemm(dqkv, x, trans_a=True, trans_w=True, out_dtype=torch.float32) if ctx.needs_input_grad[1] else None
-        dbi = ops.colsum(dqkv) if ctx.needs_input_grad[2] else None
+        dWi = _wgrad(Wi, dqkv, x) if ctx.needs_input_grad[1] else None
+        dbi = _bgrad(bi, dqkv) if ctx.needs_input_grad[2] else None
         return dx, dWi, dbi, dWo, dbo, None, None, None, None, None, None
 
 
@@ -321,7 +369,7 @@ class LayerNormFn(Function):
         y, yb = ops.layernorm(x, w.detach(), b.detach(), eps, want_bf16=bf)
         if bf:
             _fwd_put(y, yb)   # the next bf16 GEMM reads this copy instead of casting y again
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x, w, b)
         ctx.eps = eps
         ctx.autocast = bf
         ctx.bf = bf and x.shape[1] % 256 == 0 and x.shape[1] <= 1024   # the consumer of dx is a bf16 GEMM
@@ -329,19 +377,22 @@ class LayerNormFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w, b = ctx.saved_tensors
         fused = x.shape[1] % 256 == 0 and x.shape[1] <= 1024   # the one-pass kernel: can also leave dx's column sums for the consumer
+        pw, pb = _pgrad_prev(w), _pgrad_prev(b)
+        acc = (pw, pb) if (pw is not None and pb is not None) else None     # second use of this LayerNorm in the graph: add to the first's tensors
         if ctx.bf and not _LN_COLSUM:
-            dx, dw, db, dxb = ops.layernorm_bwd(x, w.detach(), dy.contiguous().float(), ctx.eps, want_bf16=True)
+            dx, dw, db, dxb = ops.layernorm_bwd(x, w.detach(), dy.contiguous().float(), ctx.eps, want_bf16=True, accum_into=acc)
             _side_put(dx, dxb)
         elif ctx.bf:
-            dx, dw, db, dxb, cs = ops.layernorm_bwd(x, w.detach(), dy.contiguous().float(), ctx.eps, want_bf16=True, want_colsum=True)
+            dx, dw, db, dxb, cs = ops.layernorm_bwd(x, w.detach(), dy.contiguous().float(), ctx.eps, want_bf16=True, want_colsum=True, accum_into=acc)
             _side_put(dx, dxb, cs)
         elif fused and not ctx.autocast and _LN_COLSUM:
-            dx, dw, db, cs = ops.layernorm_bwd(x, w.detach(), dy.contiguous().float(), ctx.eps, want_colsum=True)
+            dx, dw, db, cs = ops.layernorm_bwd(x, w.detach(), dy.contiguous().float(), ctx.eps, want_colsum=True, accum_into=acc)
             _side_put(dx, None, cs)
         else:
-            dx, dw, db = ops.layernorm_bwd(x, w.detach(), dy.contiguous().float(), ctx.eps)
+            dx, dw, db = ops.layernorm_bwd(x, w.detach(), dy.contiguous().float(), ctx.eps, accum_into=acc)
+        _pgrad_note(w, dw), _pgrad_note(b, db)
         return dx, dw, db, None
 
 

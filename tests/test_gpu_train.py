@@ -269,6 +269,47 @@ def test_scheduled_sampling_forward_train(dev):
     assert torch.equal(m2.forward_eval(batch)[1].cpu(), fx["target"])
 
 
+def test_twice_used_parameters_accumulate_in_place(dev):
+    """Scheduled sampling with 0 < teacher_forcing_prob < 1: both decoder passes carry gradient, so every decoder parameter (and the encoder's,
+    through the two passes' cross attention) gets two contributions in one backward.  The second contribution is accumulated by the
+    weight-gradient GEMM / column-sum / LayerNorm-backward kernels into the first one's tensor (autograd_path._wgrad & co.) instead of by
+    autograd's add: gradients must equal the plain form's (flag off) to summation order, and a later backward must not touch earlier tensors."""
+    from acai_omr_amd.models.models import FineTuneOMREncoder, OMRCELoss, OMRDecoder, ScheduledSamplingViTOMR
+    from acai_omr_amd.train import autograd_path as AP
+    fx = load_golden("tf_small")
+    cfg = fx["cfg"]
+    enc = FineTuneOMREncoder(cfg["P"], cfg["pe_h"], cfg["pe_w"], cfg["ft_depth"], num_layers=cfg["enc_layers"], hidden_dim=cfg["enc_dim"],
+                             num_heads=cfg["enc_heads"], mlp_dim=cfg["enc_mlp"], transformer_dropout=0.0)
+    dec = OMRDecoder(cfg["max_len"], VOCAB, num_layers=cfg["dec_layers"], hidden_dim=cfg["dec_dim"], num_heads=cfg["dec_heads"], mlp_dim=cfg["dec_mlp"],
+                     transformer_dropout=0.0)
+    m = ScheduledSamplingViTOMR(enc, None, dec, transition_head_dim=cfg["head_dim"], transition_head_dropout=0.0)
+    m.load_state_dict(fx["state_dict"])
+    m = m.to(dev).train()
+    batch = list(zip(fx["imgs"], fx["lmx"]))
+
+    def grads(fuse):
+        AP.PGRAD_FUSE = fuse
+        try:
+            m.zero_grad(set_to_none=True)
+            torch.manual_seed(11)
+            pred, tgt = m.forward_train(batch, 0.4, 0.5, False)
+            OMRCELoss(m.decoder.pad_idx)(pred, tgt).backward()
+            return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            AP.PGRAD_FUSE = True
+
+    plain, fused = grads(False), grads(True)
+    first = {n: g.clone() for n, g in fused.items()}
+    again = grads(True)                      # a second backward pass of the same model: new graph task, nothing of the first is reused
+    assert set(plain) == set(fused) == set(again)
+    for n in plain:
+        tol = 2e-5 * max(1.0, float(plain[n].abs().max()))
+        assert md(fused[n], plain[n]) < tol, n
+        assert md(again[n], plain[n]) < tol, n
+        assert torch.equal(fused[n], first[n]), n
+    assert any(n.startswith("decoder.decoder_blocks.layers.0.norm1") for n in plain)
+
+
 def test_dropout_kernels(dev):
     """Counter-based dropout: keep rate / scaling, forward-backward mask consistency, attention-probability dropout checked against
     finite differences of the forward kernel itself (same seed -> same mask) and in expectation against the undropped output."""
