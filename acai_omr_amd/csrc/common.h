@@ -93,7 +93,8 @@ struct TileLayout {
 // |x| < 8, every one of them below -3.5 where |gelu| < 1e-3 (two-piece form: 108).  t is clamped at 12: the polynomial is monotone up to there
 // (2^-258 flushes to zero), beyond it would turn upward.
 __device__ __forceinline__ float acai_half_erfc_abs(float x) {
-    const float t = fminf(fabsf(x) * 0.70710678118654752440f, 12.0f);
+    // (v_med3_f32, not fminf: the IEEE minimum first quiets its operand with an extra v_max per element)
+    const float t = __builtin_amdgcn_fmed3f(fabsf(x) * 0.70710678118654752440f, 0.0f, 12.0f);
     float q = 1.420412202e-04f;
     q = fmaf(q, t, -3.664269981e-03f);
     q = fmaf(q, t, 3.089617088e-02f);
@@ -104,7 +105,11 @@ __device__ __forceinline__ float acai_half_erfc_abs(float x) {
 }
 
 // exact-erf GELU, as torch's F.gelu(approximate="none")
-__device__ __forceinline__ float gelu_erf(float x) { return fmaf(-fabsf(x), acai_half_erfc_abs(x), fmaxf(x, 0.0f)); }
+// (max(x, 0) on the bit pattern - v_max_i32: a negative float is a negative integer; fmaxf first quiets an operand it cannot prove canonical -
+// every widened bf16 - with one more v_max per element, and v_med3(x, 0, inf) is folded back into that pair)
+__device__ __forceinline__ float gelu_erf(float x) {
+    return fmaf(-fabsf(x), acai_half_erfc_abs(x), __int_as_float(max(__float_as_int(x), 0)));
+}
 
 // d/dx of the exact-erf GELU: Phi(x) + x exp(-x^2 / 2) / sqrt(2 pi)   (log2(1 / sqrt(2 pi)) = -1.3257480647)
 __device__ __forceinline__ float gelu_erf_grad(float x) {

@@ -1310,6 +1310,7 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
             const int row = m0 + mb * 16 + lm;
             const bool rowok = row < g.M;
             f32x4 v[2];
+            uint32_t rp[2][2] = {};
             const bool swok = rowok && (sw_col + p * 32) < g.N;
             const uint32_t off_sw_c = swok ? (uint32_t)(((size_t)row * ldc + sw_col + p * 32) * 2) : OOB;
             const uint32_t off_sw_x = swok ? (uint32_t)(((size_t)row * g.ldaux + sw_col + p * 32) * 2) : OOB;
@@ -1342,13 +1343,22 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
                     for (int e = 0; e < 4; ++e) v[t][e] *= (n0 + nb * 16 + 4 * lq + e) < g.scale_cols ? g.col_scale : 1.0f;
                 }
                 if (pre_round) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[t][e] = round_bf16(v[t][e]);
+                    // rounded in PAIRS: one v_cvt_pk_bf16_f32 per two values and a shift / mask to widen them again (per value it was one
+                    // conversion + one shift: the GELU forms' epilogues are VALU-bound); the packed words are also what aux_mode 1 stores
+                    rp[t][0] = pack_bf16(v[t][0], v[t][1]);
+                    rp[t][1] = pack_bf16(v[t][2], v[t][3]);
+                    v[t][0] = __uint_as_float(rp[t][0] << 16); v[t][1] = __uint_as_float(rp[t][0] & 0xFFFF0000u);
+                    v[t][2] = __uint_as_float(rp[t][1] << 16); v[t][3] = __uint_as_float(rp[t][1] & 0xFFFF0000u);
                 }
             }
             if constexpr (aux_mode == 1) {   // keep the pre-activation
                 if constexpr (obf) {
-                    uint32_t x0 = pack_bf16(v[0][0], v[0][1]), x1 = pack_bf16(v[0][2], v[0][3]), y0 = pack_bf16(v[1][0], v[1][1]), y1 = pack_bf16(v[1][2], v[1][3]);
+                    uint32_t x0, x1, y0, y1;
+                    if (pre_round) {
+                        x0 = rp[0][0]; x1 = rp[0][1]; y0 = rp[1][0]; y1 = rp[1][1];
+                    } else {
+                        x0 = pack_bf16(v[0][0], v[0][1]); x1 = pack_bf16(v[0][2], v[0][3]); y0 = pack_bf16(v[1][0], v[1][1]); y1 = pack_bf16(v[1][2], v[1][3]);
+                    }
                     pp_swap2(x0, y0);
                     pp_swap2(x1, y1);
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{x0, x1, y0, y1}, rx, off_sw_x, 0, 0);
@@ -1372,7 +1382,7 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[t][e] = gelu_erf(v[t][e]);
-                        if (do_round) v[t][e] = round_bf16(v[t][e]);
+                        if (do_round && !obf) v[t][e] = round_bf16(v[t][e]);   // (bf16 output: the pack below is that rounding)
                     }
                 }
                 if constexpr (has_res) v[t] += __builtin_bit_cast(f32x4, prer[mb][t]);
