@@ -1261,10 +1261,9 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
     constexpr uint32_t OOB = 0xFFFFFFF0u;
     // swapped (bf16) position of this lane inside a block pair: block 2p + (lq & 1), columns 8 (lq >> 1) .. + 7
     const int sw_col = n0 + (lq & 1) * 16 + (lq >> 1) * 8;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {      // block pair outermost: only its eight per-column constants are live
-        f32x4 bias4[4];
-        bool colok[4];
+    f32x4 bias4[4];
+    bool colok[4];
+    auto take_bias = [&](int p) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int nb = 2 * p + t, col = n0 + nb * 16 + 4 * lq;
@@ -1274,15 +1273,31 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
 #pragma unroll
             for (int e = 0; e < 4; ++e) bias4[nb][e] = __shfl(bv, nb * 16 + 4 * lq + e);
         }
+    };
+    // Loop order.  Default: block pair p outermost (only its eight per-column constants are live), then two halves of four 16-row blocks.
+    // P_INNER (the GELU + kept-pre-activation form, which has the registers): 16-row block outermost, p innermost - a lane's two 64-byte
+    // halves of a 128-byte output line then leave back to back.  With p outermost they are half an epilogue apart, and under this form's
+    // 1.6 GB of stores per launch L2 evicted lines half written: WRITE_SIZE 2.24 GB for 1.61 GB of output (tools/pmc_gemm.sh).
+    constexpr bool P_INNER = MODE == (PP_OBF | PP_GELU | PP_AUX1);
+    constexpr int N_OUT = P_INNER ? 8 : 2, N_IN = 2;
+    if constexpr (P_INNER) {
+        take_bias(0);
+        take_bias(1);
+    }
+#pragma unroll
+    for (int it_o = 0; it_o < N_OUT; ++it_o) {
+        if constexpr (!P_INNER) take_bias(it_o);
         // Every load of this block pair first (the saved pre-activation of aux_mode 2, the fp32 residual: 8 or 16 x 16 bytes per lane), then
         // the arithmetic and the stores: load -> use -> store per 16 rows made a chain of 16 dependent memory round trips per epilogue
         // (~30 us per tile on the decoder's gelu' GEMM).
         // (four 16-row blocks at a time: all eight spilled the residual form)
 #pragma unroll
-        for (int mh = 0; mh < 2; ++mh) {
+        for (int it_i = 0; it_i < N_IN; ++it_i) {
+        const int p = P_INNER ? it_i : it_o;
+        const int mb_lo = P_INNER ? it_o : 4 * it_i, mb_hi = P_INNER ? it_o + 1 : 4 * it_i + 4;
         u32x4_t prex[8][2], prer[8][2];
 #pragma unroll
-        for (int mb = 4 * mh; mb < 4 * mh + 4; ++mb) {
+        for (int mb = mb_lo; mb < mb_hi; ++mb) {
             const int row = m0 + mb * 16 + lm;
             const bool rowok = row < g.M;
             if constexpr (aux_mode == 2) {
@@ -1306,7 +1321,7 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
             }
         }
 #pragma unroll
-        for (int mb = 4 * mh; mb < 4 * mh + 4; ++mb) {
+        for (int mb = mb_lo; mb < mb_hi; ++mb) {
             const int row = m0 + mb * 16 + lm;
             const bool rowok = row < g.M;
             f32x4 v[2];
