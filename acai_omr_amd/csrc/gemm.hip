@@ -1275,35 +1275,36 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
         }
     };
     // Loop order.  Default: block pair p outermost (only its eight per-column constants are live), then two halves of four 16-row blocks.
-    // P_INNER (the GELU + kept-pre-activation form, which has the registers): 16-row block outermost, p innermost - a lane's two 64-byte
-    // halves of a 128-byte output line then leave back to back.  With p outermost they are half an epilogue apart, and under this form's
-    // 1.6 GB of stores per launch L2 evicted lines half written: WRITE_SIZE 2.24 GB for 1.61 GB of output (tools/pmc_gemm.sh).
-    constexpr bool P_INNER = MODE == (PP_OBF | PP_GELU | PP_AUX1);
-    constexpr int N_OUT = P_INNER ? 8 : 2, N_IN = 2;
+    // P_INNER (the two GELU forms, bf16 output): pairs of 16-row blocks outermost, p innermost - a lane's two 64-byte halves of a 128-byte
+    // line (the stores of C and of the kept pre-activation, the loads of the saved pre-activation) are then issued back to back.  With p
+    // outermost they were half an epilogue apart, and under these forms' 1.6 GB of stores / loads per launch L2 evicted lines half written
+    // and fetched lines twice (tools/pmc_gemm.sh, M = 131072, N = 3072, K = 512: forward WRITE_SIZE 2.24 GB for 1.61 GB of output - 743 -> 633 us
+    // with this order; gelu' form FETCH_SIZE 2.2 GB for 0.94 GB of operands, WRITE_SIZE 1.08 GB for 0.81 GB).
+    constexpr bool P_INNER = obf && (aux_mode != 0);
     if constexpr (P_INNER) {
         take_bias(0);
         take_bias(1);
     }
 #pragma unroll
-    for (int it_o = 0; it_o < N_OUT; ++it_o) {
-        if constexpr (!P_INNER) take_bias(it_o);
-        // Every load of this block pair first (the saved pre-activation of aux_mode 2, the fp32 residual: 8 or 16 x 16 bytes per lane), then
+    for (int it_o = 0; it_o < 4; ++it_o) {
+        if constexpr (!P_INNER) {
+            if ((it_o & 1) == 0) take_bias(it_o >> 1);
+        }
+        // Every load of this group first (the saved pre-activation of aux_mode 2, the fp32 residual: 4 or 8 x 16 bytes per lane), then
         // the arithmetic and the stores: load -> use -> store per 16 rows made a chain of 16 dependent memory round trips per epilogue
         // (~30 us per tile on the decoder's gelu' GEMM).
-        // (four 16-row blocks at a time: all eight spilled the residual form)
-#pragma unroll
-        for (int it_i = 0; it_i < N_IN; ++it_i) {
-        const int p = P_INNER ? it_i : it_o;
-        const int mb_lo = P_INNER ? it_o : 4 * it_i, mb_hi = P_INNER ? it_o + 1 : 4 * it_i + 4;
+        // (four (block, p) slots at a time: all eight blocks of a p spilled the residual form)
         u32x4_t prex[8][2], prer[8][2];
 #pragma unroll
-        for (int mb = mb_lo; mb < mb_hi; ++mb) {
+        for (int sl = 0; sl < 4; ++sl) {
+            const int p = P_INNER ? (sl & 1) : (it_o >> 1);
+            const int mb = P_INNER ? 2 * it_o + (sl >> 1) : 4 * (it_o & 1) + sl;
             const int row = m0 + mb * 16 + lm;
             const bool rowok = row < g.M;
             if constexpr (aux_mode == 2) {
                 if constexpr (obf) {
                     const bool swok = rowok && (sw_col + p * 32) < g.N;
-                    prex[mb][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, swok ? (uint32_t)(((size_t)row * g.ldaux + sw_col + p * 32) * 2) : OOB, 0, 0);
+                    prex[mb][P_INNER ? p : 0] = __builtin_amdgcn_raw_buffer_load_b128(rx, swok ? (uint32_t)(((size_t)row * g.ldaux + sw_col + p * 32) * 2) : OOB, 0, 0);
                 } else {
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
@@ -1321,7 +1322,9 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
             }
         }
 #pragma unroll
-        for (int mb = mb_lo; mb < mb_hi; ++mb) {
+        for (int sl = 0; sl < 4; ++sl) {
+            const int p = P_INNER ? (sl & 1) : (it_o >> 1);
+            const int mb = P_INNER ? 2 * it_o + (sl >> 1) : 4 * (it_o & 1) + sl;
             const int row = m0 + mb * 16 + lm;
             const bool rowok = row < g.M;
             f32x4 v[2];
@@ -1332,7 +1335,7 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
             float a0[2][4] = {};
             if constexpr (aux_mode == 2) {
                 if constexpr (obf) {
-                    const u32x4_t L = prex[mb][0];
+                    const u32x4_t L = prex[mb][P_INNER ? p : 0];
                     uint32_t x0 = L[0], x1 = L[1], y0 = L[2], y1 = L[3];
                     pp_swap2(x0, y0);
                     pp_swap2(x1, y1);
@@ -1414,7 +1417,6 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
                 if (dbg & 128) asm volatile("" ::"v"(x0), "v"(x1), "v"(y0), "v"(y1));
                 else __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{x0, x1, y0, y1}, rc, (dbg & 64) ? (off_sw_c & 0xFFFF0u) : off_sw_c, 0, 0);
             }
-        }
         }
     }
 }
