@@ -1280,7 +1280,7 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
     // outermost they were half an epilogue apart, and under these forms' 1.6 GB of stores / loads per launch L2 evicted lines half written
     // and fetched lines twice (tools/pmc_gemm.sh, M = 131072, N = 3072, K = 512: forward WRITE_SIZE 2.24 GB for 1.61 GB of output - 743 -> 633 us
     // with this order; gelu' form FETCH_SIZE 2.2 GB for 0.94 GB of operands, WRITE_SIZE 1.08 GB for 0.81 GB).
-    constexpr bool P_INNER = obf && (aux_mode != 0);
+    constexpr bool P_INNER = obf && (aux_mode != 0);   // (the plain bf16 forms measured the same either way: their lines survive in L2)
     if constexpr (P_INNER) {
         take_bias(0);
         take_bias(1);
