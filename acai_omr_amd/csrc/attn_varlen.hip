@@ -46,8 +46,12 @@ struct AttnArgs {
     int total_q;
 };
 
-template <typename T, int DHP, bool FAST, bool DROP, bool PRE>
+// NQ = 32-query blocks per wave (1 or 2).  NQ = 2: a wave owns 64 queries and every K / V^T fragment it reads from LDS feeds two MFMAs, one per
+// block; the tile loop's fixed costs (fragment reads, staging, waits, barrier, branches: ~150 of ~600 issue cycles per 2048 scores at d_h = 32)
+// are spent once per 4096 scores.  Costs the third wave per SIMD (~200 registers).
+template <typename T, int DHP, bool FAST, bool DROP, bool PRE, int NQ = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WAVES))) void attn_fwd_kernel(AttnArgs a) {
+    constexpr int QBW = 32 * NQ, QBG = 4 * QBW;   // queries per wave / per workgroup
     constexpr int ES = sizeof(T);
     constexpr int EPC = 16 / ES;                 // elements per 16-byte chunk
     typedef TileLayout<ES, DHP> TL;              // natural [key][d] image of the K and V tiles (swizzled bf16 / padded fp32)
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WA
     const int b = blockIdx.z, h = blockIdx.y;
     const int q_start = a.cu_q[b], lq = a.cu_q[b + 1] - q_start;
     const int k_start = a.cu_k[b], lk = a.cu_k[b + 1] - k_start;
-    const int q0 = blockIdx.x * QB;
+    const int q0 = blockIdx.x * QBG;
     if (q0 >= lq) return;  // whole workgroup exits together: no barrier has been reached yet
 
     const T *Q = reinterpret_cast<const T *>(a.q) + (size_t)q_start * a.ldq + h * a.dh;
@@ -93,24 +97,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WA
     };
 
     // ---- Q fragments: lane (q = lr, half lh) keeps d = (32 s + 16 lh)/ES .. for s = 0..NS-1 -----------------
-    const int my_q = q0 + wave * 32 + lr;
-    uint4 qf[NS];
+    int my_q[NQ];
+    uint4 qf[NQ][NS];
+    f32x16 oacc[NQ][NDB];
+    float m_run[NQ], l_run[NQ];  // reference maximum (log2 domain) and this lane-half's partial row sum
 #pragma unroll
-    for (int s = 0; s < NS; ++s) qf[s] = load16(Q, a.ldq, my_q, lq, (s * 32 + lh * 16) / ES);
-
-    f32x16 oacc[NDB];
+    for (int j = 0; j < NQ; ++j) {
+        my_q[j] = q0 + wave * QBW + j * 32 + lr;
 #pragma unroll
-    for (int d = 0; d < NDB; ++d)
+        for (int s = 0; s < NS; ++s) qf[j][s] = load16(Q, a.ldq, my_q[j], lq, (s * 32 + lh * 16) / ES);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
-    float m_run = -1.0e30f, l_run = 0.f;  // reference maximum (log2 domain) and this lane-half's partial row sum
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[j][d][e] = 0.f;
+        m_run[j] = -1.0e30f;
+        l_run[j] = 0.f;
+    }
     // Row sums stay on the VALU.  Measured alternative: one extra MFMA per 16 keys with an all-ones A operand replaces the 32 adds per tile,
     // but the kernel got 20 % SLOWER (2.0 -> 2.46 ms at d_h = 32): the four dependent MFMAs per tile on one accumulator hold the wave's
     // issue port longer than the adds they replace.
 
     int nkt = (lk + KT - 1) / KT;
     if (a.causal) {
-        const int last_q = min(q0 + QB, lq) - 1;
+        const int last_q = min(q0 + QBG, lq) - 1;
         nkt = min(nkt, last_q / KT + 1);
     }
 
@@ -163,19 +172,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WA
 
     // S^T += K . Q^T of the two 32-key blocks of a tile, on top of whatever `sacc` holds.  d-slice outer, key block inner: consecutive MFMAs
     // alternate between the two accumulators (a chain of NS dependent MFMAs on one accumulator waits out the full MFMA latency at every link)
-    auto qk = [&](f32x16 (&sacc)[2], const unsigned char *ldsK) {
+    auto qk = [&](f32x16 (&sacc)[NQ][2], const unsigned char *ldsK) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                const uint4 kf = *reinterpret_cast<const uint4 *>(ldsK + TL::off(kb * 32 + lr, 2 * s + lh));
-                if constexpr (ES == 2) {
-                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
-                                                                       __builtin_bit_cast(bf16x8, qf[s]), sacc[kb], 0, 0, 0);
-                } else {
-                    const f32x4 k4 = __builtin_bit_cast(f32x4, kf), q4 = __builtin_bit_cast(f32x4, qf[s]);
+                const uint4 kf = *reinterpret_cast<const uint4 *>(ldsK + TL::off(kb * 32 + lr, 2 * s + lh));   // one read, NQ products
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(k4[e], q4[e], sacc[kb], 0, 0, 0);
+                for (int j = 0; j < NQ; ++j) {
+                    if constexpr (ES == 2) {
+                        sacc[j][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
+                                                                              __builtin_bit_cast(bf16x8, qf[j][s]), sacc[j][kb], 0, 0, 0);
+                    } else {
+                        const f32x4 k4 = __builtin_bit_cast(f32x4, kf), q4 = __builtin_bit_cast(f32x4, qf[j][s]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sacc[j][kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(k4[e], q4[e], sacc[j][kb], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -188,32 +200,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WA
     // and rows 8..15 that of query n + 16 - four 16-cycle MFMAs (8 issue cycles each) per tile on two alternating accumulators instead of 17
     // v_pk_add_f32 behind the tile's last MFMA.  The sums are those of the bf16-ROUNDED probabilities, i.e. of exactly what multiplies V.
     constexpr bool MFSUM = ACAI_ATTN_MFMA_SUM && ES == 2 && !DROP;
-    f32x4 lsum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 lsum[NQ][2];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) lsum[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const uint32_t selw = (((lane >> 4) & 1) == ((lane >> 3) & 1)) ? 0x3F803F80u : 0u;
     const uint4 sel = make_uint4(selw, selw, selw, selw);
-    auto pv = [&](f32x16 (&sacc)[2], const unsigned char *ldsV, int kt, bool sum = false) {
+    auto pv = [&](f32x16 (&sacc)[NQ][2], const unsigned char *ldsV, int kt, bool sum = false) {
         if constexpr (DROP) {
-            const uint32_t rrow = (uint32_t)(h * a.total_q + q_start + my_q);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int j = 0; j < NQ; ++j) {
+                const uint32_t rrow = (uint32_t)(h * a.total_q + q_start + my_q[j]);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const uint32_t key = (uint32_t)(kt * KT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh);
-                    sacc[kb][e] = drop_keep(a.drop_seed, rrow, key, a.drop_thr) ? sacc[kb][e] * a.drop_scale : 0.f;
-                }
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const uint32_t key = (uint32_t)(kt * KT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh);
+                        sacc[j][kb][e] = drop_keep(a.drop_seed, rrow, key, a.drop_thr) ? sacc[j][kb][e] * a.drop_scale : 0.f;
+                    }
+            }
         }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             if constexpr (ES == 2) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    uint4 pf;
-                    pf.x = pack_bf16(sacc[kb][8 * s2 + 0], sacc[kb][8 * s2 + 1]);
-                    pf.y = pack_bf16(sacc[kb][8 * s2 + 2], sacc[kb][8 * s2 + 3]);
-                    pf.z = pack_bf16(sacc[kb][8 * s2 + 4], sacc[kb][8 * s2 + 5]);
-                    pf.w = pack_bf16(sacc[kb][8 * s2 + 6], sacc[kb][8 * s2 + 7]);
-                    if constexpr (MFSUM) {
-                        if (sum) lsum[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, sel), __builtin_bit_cast(bf16x8, pf), lsum[s2], 0, 0, 0);
+                    uint4 pf[NQ];
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        pf[j].x = pack_bf16(sacc[j][kb][8 * s2 + 0], sacc[j][kb][8 * s2 + 1]);
+                        pf[j].y = pack_bf16(sacc[j][kb][8 * s2 + 2], sacc[j][kb][8 * s2 + 3]);
+                        pf[j].z = pack_bf16(sacc[j][kb][8 * s2 + 4], sacc[j][kb][8 * s2 + 5]);
+                        pf[j].w = pack_bf16(sacc[j][kb][8 * s2 + 6], sacc[j][kb][8 * s2 + 7]);
+                        if constexpr (MFSUM) {
+                            if (sum) lsum[j][s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, sel), __builtin_bit_cast(bf16x8, pf[j]), lsum[j][s2], 0, 0, 0);
+                        }
                     }
 #pragma unroll
                     for (int d = 0; d < NDB; ++d) {
@@ -226,8 +248,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WA
                         union { s4 v[2]; uint4 u; } vf;
                         vf.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(ldsV + TL::off(vrow, vchunk) + vsub));
                         vf.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(ldsV + TL::off(vrow + 8, vchunk) + vsub));
-                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf.u),
-                                                                         __builtin_bit_cast(bf16x8, pf), oacc[d], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < NQ; ++j)   // one V^T fragment, NQ products
+                            oacc[j][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf.u),
+                                                                                __builtin_bit_cast(bf16x8, pf[j]), oacc[j][d], 0, 0, 0);
                     }
                 }
             } else {
@@ -238,8 +262,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WA
                         // A for MFMA step i = 4 g4 + e: V[key e + 8 g4 + 4 lh][d]: one conflict-free ds_read_b32 per K=2 MFMA
                         const unsigned char *vr = ldsV + (kb * 32 + 8 * g4 + 4 * lh) * KPITCH + (d * 32 + lr) * 4;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(*reinterpret_cast<const float *>(vr + e * KPITCH), sacc[kb][4 * g4 + e], oacc[d], 0, 0, 0);
+                        for (int e = 0; e < 4; ++e) {
+                            const float vv = *reinterpret_cast<const float *>(vr + e * KPITCH);
+#pragma unroll
+                            for (int j = 0; j < NQ; ++j) oacc[j][d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, sacc[j][kb][4 * g4 + e], oacc[j][d], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -264,27 +291,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WA
     int n_fast = min(nkt, (a.causal ? min(lk, q0 + 1) : lk) / KT);
     bool bad = false;
     if (n_fast > 0) {
-        f32x16 s0[2];
+        f32x16 s0[NQ][2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int j = 0; j < NQ; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s0[kb][e] = 0.f;
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s0[j][kb][e] = 0.f;
         qk(s0, lds);
-        float tmax = -1.0e30f;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int j = 0; j < NQ; ++j) {
+            float tmax = -1.0e30f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, s0[kb][e]);
-        tmax *= c;
-        m_run = fmaxf(tmax, __shfl_xor(tmax, 32));
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, s0[j][kb][e]);
+            tmax *= c;
+            m_run[j] = fmaxf(tmax, __shfl_xor(tmax, 32));
+        }
     }
-    f32x16 minit;   // PRE: start value of the score accumulators
+    f32x16 minit[NQ];   // PRE: start value of the score accumulators
 #pragma unroll
-    for (int e = 0; e < 16; ++e) minit[e] = PRE ? -m_run : 0.f;
+    for (int j = 0; j < NQ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) minit[j][e] = PRE ? -m_run[j] : 0.f;
     // A wave whose 32 queries all lie past the end of the sequence (513 decoder tokens: the fifth 128-query block holds ONE row) only helps
     // with the staging: it skips the products and the softmax, which leaves the CU's issue slots to the co-resident workgroups.  Its own loop,
     // so that the working waves' loop stays one basic block.
-    const bool wave_active = q0 + wave * 32 < lq;
+    const bool wave_active = q0 + wave * QBW < lq;
     if (!wave_active) {
         for (int kt = 0; kt < n_fast; ++kt) {
             if (kt + 1 < nkt) {
@@ -300,26 +334,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WA
         auto fast_tile = [&](int kt, const unsigned char *cur, unsigned char *nxt) {
             const unsigned char *ldsK = cur, *ldsV = cur + KT * KPITCH;
             if (kt + 1 < nkt) load_tile(kt + 1);
-            f32x16 sacc[2] = {minit, minit};
+            f32x16 sacc[NQ][2];
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) sacc[j][0] = sacc[j][1] = minit[j];
             qk(sacc, ldsK);
 #if ACAI_ATTN_QK_FIRST
             __builtin_amdgcn_sched_barrier(0);   // all four S^T MFMAs first: the second key block's run under the first block's exponentials
 #endif
             // four independent partial sums: one running sum made a chain of 32 dependent v_add_f32 per tile (a dependent add issues every
             // ~6.6 cycles instead of 4: +80 cycles per tile on a loop whose floor is ~520)
-            float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int j = 0; j < NQ; ++j) {
+                float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float p = PRE ? fast_exp2(sacc[kb][e]) : fast_exp2(fmaf(sacc[kb][e], c, -m_run));
-                    sacc[kb][e] = p;
-                    if constexpr (!MFSUM) ps[ACAI_ATTN_PSUM4 ? (e & 3) : 0] += p;
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float p = PRE ? fast_exp2(sacc[j][kb][e]) : fast_exp2(fmaf(sacc[j][kb][e], c, -m_run[j]));
+                        sacc[j][kb][e] = p;
+                        if constexpr (!MFSUM) ps[ACAI_ATTN_PSUM4 ? (e & 3) : 0] += p;
+                    }
+                if constexpr (!MFSUM) {
+                    const float psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+                    bad |= !(psum < 1.2e24f);   // 2^80; also true for inf and NaN
+                    l_run[j] += psum;
                 }
-            if constexpr (!MFSUM) {
-                const float psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
-                bad |= !(psum < 1.2e24f);   // 2^80; also true for inf and NaN
-                l_run += psum;
             }
             pv(sacc, ldsV, kt, true);
             if (kt + 1 < nkt) store_tile(nxt);
@@ -336,20 +375,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WA
         // rows 0..7 (any register of lanes 0..31) hold the sum of query n = lane & 15, rows 8..15 (lanes 32..63) that of query n + 16; l_run is
         // a per-lane-half partial sum (the halves meet after the loops), so the whole sum goes to the lower half.  One check for the whole
         // loop: a probability beyond 2^100 (or inf / NaN) shows in its row's sum
-        const float full = __shfl(lsum[0][0] + lsum[1][0], (lane & 16) ? 32 + (lane & 15) : (lane & 15));
-        if (wave_active && n_fast > 0) {
-            bad = !(full < 1.2e30f);
-            l_run = lh == 0 ? full : 0.f;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const float full = __shfl(lsum[j][0][0] + lsum[j][1][0], (lane & 16) ? 32 + (lane & 15) : (lane & 15));
+            if (wave_active && n_fast > 0) {
+                bad |= !(full < 1.2e30f);
+                l_run[j] = lh == 0 ? full : 0.f;
+            }
         }
     }
     int kt0 = n_fast;
     if (n_fast > 0 && __syncthreads_or(bad)) {   // start over with a running maximum (all waves: the barrier count must match)
 #pragma unroll
-        for (int d = 0; d < NDB; ++d)
+        for (int j = 0; j < NQ; ++j) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
-        m_run = -1.0e30f;
-        l_run = 0.f;
+            for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[j][d][e] = 0.f;
+            m_run[j] = -1.0e30f;
+            l_run[j] = 0.f;
+        }
         kt0 = 0;
         stage_at(0);
         load_tile(0);
@@ -370,107 +415,115 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WA
     for (int kt = kt0; kt < nkt; ++kt) {
         const unsigned char *ldsK = lds + (kt & 1) * STAGE, *ldsV = ldsK + KT * KPITCH;
         if (kt + 1 < nkt) load_tile(kt + 1);
-        f32x16 sacc[2];
+        f32x16 sacc[NQ][2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int j = 0; j < NQ; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sacc[j][kb][e] = 0.f;
         qk(sacc, ldsK);
 
         // ---- mask + online softmax (per-lane query) ----------------------------------------------------
-        const int key_lim = a.causal ? min(lk, my_q + 1) : lk;  // keys < key_lim are attended
-        const int wave_lim = a.causal ? min(lk, q0 + wave * 32 + 1) : lk;  // keys < wave_lim are valid for ALL lanes of the wave
-        // Lazy rescale: the running maximum is only raised (and O, l rescaled) when some lane's tile maximum exceeds it by more than 2^8;
-        // otherwise probabilities are taken against the stale maximum (p <= 256: exact in the final O / l ratio up to rounding).
-        auto raise_max = [&](float tmax) {
-            if (__builtin_amdgcn_ballot_w64(tmax > m_run + 8.0f) != 0) {  // wave-uniform
-                const float m2 = fmaxf(m_run, tmax);
-                const float alpha = fast_exp2(m_run - m2);
-                m_run = m2;
-                l_run *= alpha;
+        const int wave_lim = a.causal ? min(lk, q0 + wave * QBW + 1) : lk;  // keys < wave_lim are valid for ALL lanes of the wave
 #pragma unroll
-                for (int d = 0; d < NDB; ++d)
+        for (int j = 0; j < NQ; ++j) {
+            const int key_lim = a.causal ? min(lk, my_q[j] + 1) : lk;  // keys < key_lim are attended
+            // Lazy rescale: the running maximum is only raised (and O, l rescaled) when some lane's tile maximum exceeds it by more than 2^8;
+            // otherwise probabilities are taken against the stale maximum (p <= 256: exact in the final O / l ratio up to rounding).
+            auto raise_max = [&](float tmax) {
+                if (__builtin_amdgcn_ballot_w64(tmax > m_run[j] + 8.0f) != 0) {  // wave-uniform
+                    const float m2 = fmaxf(m_run[j], tmax);
+                    const float alpha = fast_exp2(m_run[j] - m2);
+                    m_run[j] = m2;
+                    l_run[j] *= alpha;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+                    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) oacc[j][d][e] *= alpha;
+                }
+            };
+            float psum = 0.f;
+            if ((kt + 1) * KT <= wave_lim) {
+                float tmax = -1.0e30f;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[j][kb][e]);
+                tmax *= c;
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+                raise_max(tmax);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float p = fast_exp2(fmaf(sacc[j][kb][e], c, -m_run[j]));
+                        sacc[j][kb][e] = p;
+                        psum += p;
+                    }
+            } else {
+                float tmax = -1.0e30f;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = kt * KT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                        const float sv = key < key_lim ? sacc[j][kb][e] * c : -1.0e30f;
+                        sacc[j][kb][e] = sv;
+                        tmax = fmaxf(tmax, sv);
+                    }
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+                raise_max(tmax);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        // masked entries: gate on the mask value itself (a fully masked row keeps m = -1e30 and exp2(0) = 1 would be wrong)
+                        const float p = sacc[j][kb][e] > -0.5e30f ? fast_exp2(sacc[j][kb][e] - m_run[j]) : 0.f;
+                        sacc[j][kb][e] = p;
+                        psum += p;
+                    }
             }
-        };
-        float psum = 0.f;
-        if ((kt + 1) * KT <= wave_lim) {
-            float tmax = -1.0e30f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[kb][e]);
-            tmax *= c;
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            raise_max(tmax);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float p = fast_exp2(fmaf(sacc[kb][e], c, -m_run));
-                    sacc[kb][e] = p;
-                    psum += p;
-                }
-        } else {
-            float tmax = -1.0e30f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int key = kt * KT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    const float sv = key < key_lim ? sacc[kb][e] * c : -1.0e30f;
-                    sacc[kb][e] = sv;
-                    tmax = fmaxf(tmax, sv);
-                }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            raise_max(tmax);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    // masked entries: gate on the mask value itself (a fully masked row keeps m = -1e30 and exp2(0) = 1 would be wrong)
-                    const float p = sacc[kb][e] > -0.5e30f ? fast_exp2(sacc[kb][e] - m_run) : 0.f;
-                    sacc[kb][e] = p;
-                    psum += p;
-                }
+            l_run[j] += psum;
         }
-        l_run += psum;
         pv(sacc, ldsV, kt);
         if (kt + 1 < nkt) store_tile(lds + ((kt + 1) & 1) * STAGE);
         __syncthreads();   // one barrier per tile: stage (kt+1)&1 was last read in iteration kt-1
     }
 
     // ---- normalise and store: lane owns query my_q, registers hold d = db*32 + (e&3) + 8*(e>>2) + 4*lh ------
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    if (a.lse && my_q < lq && lh == 0) a.lse[(size_t)h * a.total_q + q_start + my_q] = m_run + log2f(l_tot);
-    if (my_q < lq) {
-        T *orow = O + (size_t)my_q * a.ldo;
 #pragma unroll
-        for (int d = 0; d < NDB; ++d)
+    for (int j = 0; j < NQ; ++j) {
+        const float l_tot = l_run[j] + __shfl_xor(l_run[j], 32);
+        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        if (a.lse && my_q[j] < lq && lh == 0) a.lse[(size_t)h * a.total_q + q_start + my_q[j]] = m_run[j] + log2f(l_tot);
+        if (my_q[j] < lq) {
+            T *orow = O + (size_t)my_q[j] * a.ldo;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d0 = d * 32 + 8 * g4 + 4 * lh;
-                if constexpr (FAST) {
-                    if (d0 < dh) {
-                        if constexpr (ES == 2) {
-                            uint2 p;
-                            p.x = pack_bf16(oacc[d][4 * g4 + 0] * inv, oacc[d][4 * g4 + 1] * inv);
-                            p.y = pack_bf16(oacc[d][4 * g4 + 2] * inv, oacc[d][4 * g4 + 3] * inv);
-                            *reinterpret_cast<uint2 *>(orow + d0) = p;
-                        } else {
-                            float4 p = make_float4(oacc[d][4 * g4 + 0] * inv, oacc[d][4 * g4 + 1] * inv,
-                                                   oacc[d][4 * g4 + 2] * inv, oacc[d][4 * g4 + 3] * inv);
-                            *reinterpret_cast<float4 *>(orow + d0) = p;
+            for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d0 = d * 32 + 8 * g4 + 4 * lh;
+                    if constexpr (FAST) {
+                        if (d0 < dh) {
+                            if constexpr (ES == 2) {
+                                uint2 p;
+                                p.x = pack_bf16(oacc[j][d][4 * g4 + 0] * inv, oacc[j][d][4 * g4 + 1] * inv);
+                                p.y = pack_bf16(oacc[j][d][4 * g4 + 2] * inv, oacc[j][d][4 * g4 + 3] * inv);
+                                *reinterpret_cast<uint2 *>(orow + d0) = p;
+                            } else {
+                                float4 p = make_float4(oacc[j][d][4 * g4 + 0] * inv, oacc[j][d][4 * g4 + 1] * inv,
+                                                       oacc[j][d][4 * g4 + 2] * inv, oacc[j][d][4 * g4 + 3] * inv);
+                                *reinterpret_cast<float4 *>(orow + d0) = p;
+                            }
                         }
-                    }
-                } else {
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (d0 + e < dh) DT<T>::st(orow + d0 + e, oacc[d][4 * g4 + e] * inv);
+                        for (int e = 0; e < 4; ++e)
+                            if (d0 + e < dh) DT<T>::st(orow + d0 + e, oacc[j][d][4 * g4 + e] * inv);
+                    }
                 }
-            }
+        }
     }
 }
 
@@ -486,7 +539,14 @@ int launch(const AttnArgs &a, int B, int max_q, bool pre, hipStream_t st) {
         if (!fast) return acai_set_err(-1, "acai_attn_varlen_fwd: q_prescaled needs 16-byte aligned operands and d_h %% %d == 0", EPC);
         if (a.drop_thr)
             hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, true, true, true>), grid, dim3(256), 0, st, a);
-        else
+        else if constexpr (sizeof(T) == 2) {
+            // the training steps' form: two query blocks per wave (ACAI_ATTN_NQ=1: one, A/B aid) when the sequences are long enough to fill the chip
+            static const int nq_env = getenv("ACAI_ATTN_NQ") ? atoi(getenv("ACAI_ATTN_NQ")) : 2;
+            if (DHP == 32 && nq_env == 2 && max_q >= 512)   // (d_h = 64: two blocks need more than 256 registers - it spilt 95 of them into the loop)
+                hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, true, false, true, 2>), dim3(cdiv(max_q, 2 * QB), a.H, B), dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, true, false, true>), grid, dim3(256), 0, st, a);
+        } else
             hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, true, false, true>), grid, dim3(256), 0, st, a);
     } else if (a.drop_thr) {
         if (fast)
