@@ -615,6 +615,315 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) 
     }
 }
 
+// ---- two lane-owned 32-row blocks per wave (round 3) ---------------------------------------------------------------------------------------
+// The training steps' hot form - bf16, q prescaled, no dropout, no causal mask, d_h <= 32 - with a wave owning 64 queries (dQ) or 64 keys
+// (dK / dV): every fragment it reads from the streamed tile (ds_read_b128 of the rows, ds_read_b64_tr_b16 of the transposed image) feeds
+// TWO MFMAs, one per owned block, and the tile loop's fixed costs (staging, statistics reads, waits, barrier, branches) are spent once per
+// 4096 scores instead of 2048.  The kernels are bound by the issue port (section 5 of DESIGN.md): dQ 126 -> ~108, dK/dV 179 -> ~150
+// instructions per 2048 scores.  Costs the third wave per SIMD (~210-230 registers).  Same arithmetic, same summation order per output as the
+// one-block kernels above (which keep every other case: causal masks, dropout, fp32, d_h = 64).
+template <int NQ, int NS>
+__device__ __forceinline__ void mma_rows2q(f32x16 (&acc0)[NQ], const unsigned char *tile0, const uint4 (&bf0)[NQ][NS], f32x16 (&acc1)[NQ],
+                                           const unsigned char *tile1, const uint4 (&bf1)[NQ][NS], int r0, int lr, int lh) {
+    typedef TileLayout<2, 32> TL;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int o = TL::off(r0 + lr, 2 * s + lh);
+        const uint4 a0 = *reinterpret_cast<const uint4 *>(tile0 + o), a1 = *reinterpret_cast<const uint4 *>(tile1 + o);   // one read each, NQ products
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, bf0[j][s]), acc0[j], 0, 0, 0);
+            acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, bf1[j][s]), acc1[j], 0, 0, 0);
+        }
+    }
+}
+
+// acc[j] += tile^T . x[j] (see mma_acc): the transposed A fragment is read once for the NQ accumulator tiles
+template <int NQ>
+__device__ __forceinline__ void mma_accq(f32x16 (&acc)[NQ], const unsigned char *tile, int r0, int lane, const f32x16 (&x)[NQ]) {
+    typedef TileLayout<2, 32> TL;
+    typedef __attribute__((ext_vector_type(4))) short s4;
+    typedef __attribute__((address_space(3))) s4 *lds_s4;
+    const int lh = lane >> 5, i16 = lane & 15, g1 = (lane >> 4) & 1;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int row = r0 + 16 * s2 + 4 * lh + (i16 >> 2), chunk = 2 * g1 + ((i16 & 3) >> 1), sub = 8 * (i16 & 1);
+        union { s4 v[2]; uint4 u; } af;
+        af.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(tile + TL::off(row, chunk) + sub));
+        af.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(tile + TL::off(row + 8, chunk) + sub));
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            uint4 xf;
+            xf.x = pack_bf16(x[j][8 * s2 + 0], x[j][8 * s2 + 1]);
+            xf.y = pack_bf16(x[j][8 * s2 + 2], x[j][8 * s2 + 3]);
+            xf.z = pack_bf16(x[j][8 * s2 + 4], x[j][8 * s2 + 5]);
+            xf.w = pack_bf16(x[j][8 * s2 + 6], x[j][8 * s2 + 7]);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af.u), __builtin_bit_cast(bf16x8, xf), acc[j], 0, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dq2_kernel(BwdArgs a) {
+    typedef bf16_t T;
+    constexpr int NQ = 2, DHP = 32, RP = TileLayout<2, DHP>::PITCH, NS = 2, STAGE = 2 * TT * RP, QBW = 32 * NQ, QBG = 4 * QBW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // two stages of {K tile, V tile}
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q_start = a.cu_q[b], lq = a.cu_q[b + 1] - q_start;
+    const int k_start = a.cu_k[b], lk = a.cu_k[b + 1] - k_start;
+    const int q0 = blockIdx.x * QBG;
+    if (q0 >= lq) return;
+    const int dh = a.dh;
+    const T *Q = reinterpret_cast<const T *>(a.q) + (size_t)q_start * a.ldq + h * dh;
+    const T *K = reinterpret_cast<const T *>(a.k) + (size_t)k_start * a.ldk + h * dh;
+    const T *V = reinterpret_cast<const T *>(a.v) + (size_t)k_start * a.ldv + h * dh;
+    const T *DO = reinterpret_cast<const T *>(a.dout) + (size_t)q_start * a.lddo + h * dh;
+    const T *O = reinterpret_cast<const T *>(a.o) + (size_t)q_start * a.ldo + h * dh;
+    T *DQ = reinterpret_cast<T *>(a.dq) + (size_t)q_start * a.lddq + h * dh;
+
+    int my_q[NQ];
+    uint4 qf[NQ][NS], dof[NQ][NS];
+    f32x16 dqacc[NQ], sinit[NQ], pinit[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        my_q[j] = q0 + wave * QBW + j * 32 + lr;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            qf[j][s] = ld16<T, true>(Q, a.ldq, my_q[j], lq, s * 16 + lh * 8, dh);
+            dof[j][s] = ld16<T, true>(DO, a.lddo, my_q[j], lq, s * 16 + lh * 8, dh);
+        }
+        const size_t sidx = (size_t)h * a.total_q + q_start + (my_q[j] < lq ? my_q[j] : 0);
+        const float lse = a.lse[sidx];
+        float dlt = 0.f;   // delta[q] = sum_d dO[q,d] O[q,d], published (negated) for the dK/dV kernel - see attn_bwd_dq_kernel
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const uint4 of = ld16<T, true>(O, a.ldo, my_q[j], lq, s * 16 + lh * 8, dh);
+            const uint32_t ow[4] = {of.x, of.y, of.z, of.w}, dw[4] = {dof[j][s].x, dof[j][s].y, dof[j][s].z, dof[j][s].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dlt = fmaf(__uint_as_float(ow[e] << 16), __uint_as_float(dw[e] << 16), dlt);
+                dlt = fmaf(__uint_as_float(ow[e] & 0xffff0000u), __uint_as_float(dw[e] & 0xffff0000u), dlt);
+            }
+        }
+        dlt += __shfl_xor(dlt, 32);
+        if (lh == 0 && my_q[j] < lq) const_cast<float *>(a.delta)[sidx] = -dlt;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            dqacc[j][e] = 0.f;
+            sinit[j][e] = -lse;     // the score accumulators start at -lse, dP at -delta: the MFMAs leave (score - lse) and (dP - delta)
+            pinit[j][e] = -dlt;
+        }
+    }
+    const int nkt = (lk + TT - 1) / TT;
+    TileStager<T, DHP, true> stg;
+    stg.init(K, a.ldk, V, a.ldv, tid, dh, 0);
+    stg.load(0, lk);
+    stg.store(smem);
+    __syncthreads();
+    const bool wave_active = q0 + wave * QBW < lq;
+    if (!wave_active) {   // (only helps with the staging: see attn_fwd_kernel)
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (kt + 1 < nkt) {
+                stg.load(kt + 1, lk);
+                stg.store(smem + ((kt + 1) & 1) * STAGE);
+            }
+            __syncthreads();
+        }
+    } else {
+        auto tile = [&](int kt, const unsigned char *cur, unsigned char *nxt, bool masked) {
+            const unsigned char *ldsK = cur, *ldsV = cur + TT * RP;
+            if (kt + 1 < nkt) stg.load(kt + 1, lk);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                if (masked && kt * TT + kb * 32 >= lk) continue;   // a 32-key block entirely past the sequence end
+                f32x16 sc[NQ], dp[NQ];
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    sc[j] = sinit[j];
+                    dp[j] = pinit[j];
+                }
+                mma_rows2q<NQ, NS>(sc, ldsK, qf, dp, ldsV, dof, kb * 32, lr, lh);    // S^T[key][q] - lse and dP^T[key][q] - delta
+#pragma unroll
+                for (int j = 0; j < NQ; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float pr = fast_exp2(sc[j][e]);
+                        if (masked) pr = (kt * TT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) < lk ? pr : 0.f;
+                        sc[j][e] = pr * dp[j][e];   // dS^T
+                    }
+                mma_accq<NQ>(dqacc, ldsK, kb * 32, lane, sc);   // dQ^T += K^T dS^T
+            }
+            if (kt + 1 < nkt) stg.store(nxt);
+            __syncthreads();
+        };
+        const int n_fast = lk / TT;   // tiles with every key valid
+        int kt = 0;
+        for (; kt + 1 < n_fast; kt += 2) {   // (unrolled by two: the LDS stages are compile-time offsets)
+            tile(kt, smem, smem + STAGE, false);
+            tile(kt + 1, smem + STAGE, smem, false);
+        }
+        if (kt < n_fast) {
+            tile(kt, smem, smem + STAGE, false);
+            ++kt;
+        }
+        for (; kt < nkt; ++kt) tile(kt, smem + (kt & 1) * STAGE, smem + ((kt + 1) & 1) * STAGE, true);
+    }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        if (my_q[j] >= lq) continue;
+        T *row = DQ + (size_t)my_q[j] * a.lddq;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d0 = 8 * g4 + 4 * lh;   // registers 4 g4 .. 4 g4 + 3 are four consecutive d: one 8-byte store
+            if (d0 < dh) {
+                uint2 pk;
+                pk.x = pack_bf16(dqacc[j][4 * g4 + 0] * a.scale, dqacc[j][4 * g4 + 1] * a.scale);
+                pk.y = pack_bf16(dqacc[j][4 * g4 + 2] * a.scale, dqacc[j][4 * g4 + 3] * a.scale);
+                *reinterpret_cast<uint2 *>(row + d0) = pk;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv2_kernel(BwdArgs a) {
+    typedef bf16_t T;
+    constexpr int NK = 2, DHP = 32, RP = TileLayout<2, DHP>::PITCH, NS = 2, STAGE = 2 * TT * RP + 2 * TT * (int)sizeof(float), KBW = 32 * NK, KBG = 4 * KBW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // two stages of {Q tile, dO tile, -lse[64], -delta[64]}
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q_start = a.cu_q[b], lq = a.cu_q[b + 1] - q_start;
+    const int k_start = a.cu_k[b], lk = a.cu_k[b + 1] - k_start;
+    const int k0 = blockIdx.x * KBG;
+    if (k0 >= lk) return;
+    const int dh = a.dh;
+    const T *Q = reinterpret_cast<const T *>(a.q) + (size_t)q_start * a.ldq + h * dh;
+    const T *K = reinterpret_cast<const T *>(a.k) + (size_t)k_start * a.ldk + h * dh;
+    const T *V = reinterpret_cast<const T *>(a.v) + (size_t)k_start * a.ldv + h * dh;
+    const T *DO = reinterpret_cast<const T *>(a.dout) + (size_t)q_start * a.lddo + h * dh;
+    T *DK = reinterpret_cast<T *>(a.dk) + (size_t)k_start * a.lddk + h * dh;
+    T *DV = reinterpret_cast<T *>(a.dv) + (size_t)k_start * a.lddv + h * dh;
+
+    int my_k[NK];
+    uint4 kf[NK][NS], vf[NK][NS];
+    f32x16 dkacc[NK], dvacc[NK];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        my_k[j] = k0 + wave * KBW + j * 32 + lr;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            kf[j][s] = ld16<T, true>(K, a.ldk, my_k[j], lk, s * 16 + lh * 8, dh);
+            vf[j][s] = ld16<T, true>(V, a.ldv, my_k[j], lk, s * 16 + lh * 8, dh);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dkacc[j][e] = dvacc[j][e] = 0.f;
+    }
+    const int nqt = (lq + TT - 1) / TT;
+    TileStager<T, DHP, true> stg;
+    stg.init(Q, a.ldq, DO, a.lddo, tid, dh, 0);
+    const float *lse_row = a.lse + (size_t)h * a.total_q + q_start, *dlt_row = a.delta + (size_t)h * a.total_q + q_start;
+    // one query row's statistics per thread (every thread issues the load, see attn_bwd_dkv_kernel); -delta arrives negated, lse is negated here
+    float r_stat = 0.f;
+    const float *stat_row = (tid & 64) ? dlt_row : lse_row;
+    auto load_stats = [&](int qt) {
+        const int qq = qt * TT + (tid & 63);
+        r_stat = stat_row[qq < lq ? qq : 0];
+    };
+    auto store_stats = [&](unsigned char *stage) {
+        if (tid < 2 * TT) reinterpret_cast<float *>(stage + 2 * TT * RP)[tid] = (tid & 64) ? r_stat : -r_stat;
+    };
+    stg.load(0, lq);
+    load_stats(0);
+    stg.store(smem);
+    store_stats(smem);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the K / V fragments are complete on every path into the loop (see attn_bwd_dkv_kernel)
+    __syncthreads();
+    const bool wave_active = k0 + wave * KBW < lk;   // a wave whose 64 keys all lie past the end only stages
+    auto tile = [&](int qt, const unsigned char *cur, unsigned char *nxt, bool masked) {
+        if (qt + 1 < nqt) {
+            stg.load(qt + 1, lq);
+            load_stats(qt + 1);
+        }
+        if (wave_active) {
+            const float *ldsNlse = reinterpret_cast<const float *>(cur + 2 * TT * RP), *ldsNdl = ldsNlse + TT;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                if (masked && qt * TT + qb * 32 >= lq) continue;   // a 32-query block entirely past the sequence end
+                // the 16 query rows a lane holds are rows 8 g4 + 4 lh + (0..3): their -lse / -delta as the accumulators' start values, read
+                // once for both key blocks
+                f32x16 nl, nd;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 l4 = *reinterpret_cast<const f32x4 *>(ldsNlse + qb * 32 + 8 * g4 + 4 * lh);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4 *>(ldsNdl + qb * 32 + 8 * g4 + 4 * lh);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        nl[4 * g4 + i] = l4[i];
+                        nd[4 * g4 + i] = d4[i];
+                    }
+                }
+                f32x16 sc[NK], dp[NK];
+#pragma unroll
+                for (int j = 0; j < NK; ++j) {
+                    sc[j] = nl;
+                    dp[j] = nd;
+                }
+                mma_rows2q<NK, NS>(sc, cur, kf, dp, cur + TT * RP, vf, qb * 32, lr, lh);   // S[q][key] - lse and dP[q][key] - delta
+#pragma unroll
+                for (int j = 0; j < NK; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float pr = fast_exp2(sc[j][e]);
+                        if (masked) {
+                            const int qq = qt * TT + qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                            pr = (qq < lq && my_k[j] < lk) ? pr : 0.f;
+                        }
+                        sc[j][e] = pr;                 // P
+                        dp[j][e] = pr * dp[j][e];      // dS
+                    }
+                mma_accq<NK>(dvacc, cur + TT * RP, qb * 32, lane, sc);   // dV^T += dO^T P
+                mma_accq<NK>(dkacc, cur, qb * 32, lane, dp);             // dK^T += Q^T dS
+            }
+        }
+        if (qt + 1 < nqt) {
+            stg.store(nxt);
+            store_stats(nxt);
+        }
+        __syncthreads();
+    };
+    {
+        const int n_fast = (k0 + KBG <= lk) ? lq / TT : 0;   // every key of the workgroup and every query of the tile valid
+        int qt = 0;
+        for (; qt + 1 < n_fast; qt += 2) {
+            tile(qt, smem, smem + STAGE, false);
+            tile(qt + 1, smem + STAGE, smem, false);
+        }
+        if (qt < n_fast) {
+            tile(qt, smem, smem + STAGE, false);
+            ++qt;
+        }
+        for (; qt < nqt; ++qt) tile(qt, smem + (qt & 1) * STAGE, smem + ((qt + 1) & 1) * STAGE, true);
+    }
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        if (my_k[j] >= lk) continue;
+        T *rk = DK + (size_t)my_k[j] * a.lddk, *rv = DV + (size_t)my_k[j] * a.lddv;
+        const float ksc = 0.6931471805599453f;   // dK = dS^T Q = dS^T Q' sqrt(d_h) / log2(e), times 1 / sqrt(d_h)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d0 = 8 * g4 + 4 * lh;
+            if (d0 < dh) {
+                uint2 pk, pv;
+                pk.x = pack_bf16(dkacc[j][4 * g4 + 0] * ksc, dkacc[j][4 * g4 + 1] * ksc);
+                pk.y = pack_bf16(dkacc[j][4 * g4 + 2] * ksc, dkacc[j][4 * g4 + 3] * ksc);
+                pv.x = pack_bf16(dvacc[j][4 * g4 + 0], dvacc[j][4 * g4 + 1]);
+                pv.y = pack_bf16(dvacc[j][4 * g4 + 2], dvacc[j][4 * g4 + 3]);
+                *reinterpret_cast<uint2 *>(rk + d0) = pk;
+                *reinterpret_cast<uint2 *>(rv + d0) = pv;
+            }
+        }
+    }
+}
+
 template <typename T, int DHP>
 int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, bool pre, hipStream_t st) {
     constexpr int ES = sizeof(T), EPC = 16 / ES;
@@ -633,6 +942,21 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, bool pre, hipStrea
             attr = true;
         }
         dim3 gq(cdiv(max_q, OB), a.H, B), gk(cdiv(max_k, OB), a.H, B);
+        if constexpr (sizeof(T) == 2 && DHP == 32 && F && !D && P) {
+            // the training steps' form on long sequences: two lane-owned blocks per wave (ACAI_ATTN_NQ=1: the one-block kernels, A/B aid)
+            static const int nq_env = getenv("ACAI_ATTN_NQ") ? atoi(getenv("ACAI_ATTN_NQ")) : 2;
+            static bool attr2 = false;
+            if (!attr2) {
+                hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                attr2 = true;
+            }
+            if (nq_env == 2 && !a.causal && max_q >= 512 && max_k >= 512) {
+                hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(cdiv(max_q, 2 * OB), a.H, B), dim3(256), lds_dq, st, a);
+                hipLaunchKernelGGL(attn_bwd_dkv2_kernel, dim3(cdiv(max_k, 2 * OB), a.H, B), dim3(256), lds_dkv, st, a);
+                return;
+            }
+        }
         hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DHP, F, D, P>), gq, dim3(256), lds_dq, st, a);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DHP, F, D, P>), gk, dim3(256), lds_dkv, st, a);
     };

@@ -113,6 +113,11 @@ def ref_attn(q, k, v, lens_q, lens_k, H, dh, causal):
     (2, 64, [300], None, True),
     (12, 64, [1024], None, False),
     (1, 10, [70], None, True),
+    # >= 512 queries, d_h <= 32, bf16 prescaled: the two-blocks-per-wave forward (ragged ends, a 1-row sequence, cross lengths, causal)
+    (3, 32, [513, 640, 1], None, False),
+    (2, 32, [600, 513], [1000, 577], False),
+    (2, 32, [700, 130], None, True),
+    (2, 24, [520], [64], False),
 ])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("prescaled", [False, True])

@@ -53,6 +53,11 @@ def test_gemm_transposed_variants(dev, M, N, K, dtype):
     (2, 64, [300], None, True),
     (2, 32, [333, 128], None, False),      # several full tiles in front of a ragged one
     (1, 64, [256], [400], False),
+    # >= 512 queries and keys, d_h <= 32, bf16 prescaled, no mask: the two-blocks-per-wave backward kernels (ragged ends in both directions,
+    # a workgroup whose last waves own no row, cross lengths)
+    (2, 32, [513, 700], None, False),
+    (2, 32, [600, 513], [1000, 577], False),
+    (1, 24, [1025], [512], False),
 ])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("prescaled", [False, True])
