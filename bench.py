@@ -302,7 +302,9 @@ def bench_tf_step(dev, batch, height, width, T, steps):
         loss.backward()
         return loss
 
-    dt, loss = _timed_steps(step, steps, None, dev)
+    # two warm-up steps: scheduled sampling draws a different number of positions each step, so the allocator's pool is only settled after a second one
+    # (with one, a timed step now and then paid a device allocation: 201 ms against 172)
+    dt, loss = _timed_steps(step, steps, None, dev, warm=2)
     n = (height // PATCH_SIZE) * (width // PATCH_SIZE)
     step_flops = 3 * flops_tf_fwd(n, T + 1) * batch
     ms = dt / steps * 1e3
