@@ -172,11 +172,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WA
 
     // S^T += K . Q^T of the two 32-key blocks of a tile, on top of whatever `sacc` holds.  d-slice outer, key block inner: consecutive MFMAs
     // alternate between the two accumulators (a chain of NS dependent MFMAs on one accumulator waits out the full MFMA latency at every link)
-    auto qk = [&](f32x16 (&sacc)[NQ][2], const unsigned char *ldsK) {
+    auto qk = [&](f32x16 (&sacc)[NQ][2], const unsigned char *ldsK, int kb_lo = 0, int kb_hi = 2) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = kb_lo; kb < kb_hi; ++kb) {
                 const uint4 kf = *reinterpret_cast<const uint4 *>(ldsK + TL::off(kb * 32 + lr, 2 * s + lh));   // one read, NQ products
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WA
         for (int i = 0; i < 2; ++i) lsum[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const uint32_t selw = (((lane >> 4) & 1) == ((lane >> 3) & 1)) ? 0x3F803F80u : 0u;
     const uint4 sel = make_uint4(selw, selw, selw, selw);
-    auto pv = [&](f32x16 (&sacc)[NQ][2], const unsigned char *ldsV, int kt, bool sum = false) {
+    auto pv = [&](f32x16 (&sacc)[NQ][2], const unsigned char *ldsV, int kt, bool sum = false, int kb_lo = 0, int kb_hi = 2) {
         if constexpr (DROP) {
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WA
             }
         }
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = kb_lo; kb < kb_hi; ++kb) {
             if constexpr (ES == 2) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -335,32 +335,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WA
             const unsigned char *ldsK = cur, *ldsV = cur + KT * KPITCH;
             if (kt + 1 < nkt) load_tile(kt + 1);
             f32x16 sacc[NQ][2];
+            // NQ = 1: both 32-key blocks of the tile in flight (the second block's products run under the first block's exponentials).
+            // NQ = 2 at d_h = 64: one key block at a time for both query blocks - four score tiles at once do not fit the registers
+            constexpr int KSTEP = (NQ == 2 && DHP == 64) ? 1 : 2;
 #pragma unroll
-            for (int j = 0; j < NQ; ++j) sacc[j][0] = sacc[j][1] = minit[j];
-            qk(sacc, ldsK);
+            for (int k0 = 0; k0 < 2; k0 += KSTEP) {
+#pragma unroll
+                for (int j = 0; j < NQ; ++j)
+#pragma unroll
+                    for (int kb = k0; kb < k0 + KSTEP; ++kb) sacc[j][kb] = minit[j];
+                qk(sacc, ldsK, k0, k0 + KSTEP);
 #if ACAI_ATTN_QK_FIRST
-            __builtin_amdgcn_sched_barrier(0);   // all four S^T MFMAs first: the second key block's run under the first block's exponentials
+                __builtin_amdgcn_sched_barrier(0);   // all four S^T MFMAs first: the second key block's run under the first block's exponentials
 #endif
-            // four independent partial sums: one running sum made a chain of 32 dependent v_add_f32 per tile (a dependent add issues every
-            // ~6.6 cycles instead of 4: +80 cycles per tile on a loop whose floor is ~520)
+                // four independent partial sums: one running sum made a chain of 32 dependent v_add_f32 per tile (a dependent add issues every
+                // ~6.6 cycles instead of 4: +80 cycles per tile on a loop whose floor is ~520)
 #pragma unroll
-            for (int j = 0; j < NQ; ++j) {
-                float ps[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < NQ; ++j) {
+                    float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                    for (int kb = k0; kb < k0 + KSTEP; ++kb)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const float p = PRE ? fast_exp2(sacc[j][kb][e]) : fast_exp2(fmaf(sacc[j][kb][e], c, -m_run[j]));
-                        sacc[j][kb][e] = p;
-                        if constexpr (!MFSUM) ps[ACAI_ATTN_PSUM4 ? (e & 3) : 0] += p;
+                        for (int e = 0; e < 16; ++e) {
+                            const float p = PRE ? fast_exp2(sacc[j][kb][e]) : fast_exp2(fmaf(sacc[j][kb][e], c, -m_run[j]));
+                            sacc[j][kb][e] = p;
+                            if constexpr (!MFSUM) ps[ACAI_ATTN_PSUM4 ? (e & 3) : 0] += p;
+                        }
+                    if constexpr (!MFSUM) {
+                        const float psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+                        bad |= !(psum < 1.2e24f);   // 2^80; also true for inf and NaN
+                        l_run[j] += psum;
                     }
-                if constexpr (!MFSUM) {
-                    const float psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
-                    bad |= !(psum < 1.2e24f);   // 2^80; also true for inf and NaN
-                    l_run[j] += psum;
                 }
+                pv(sacc, ldsV, kt, true, k0, k0 + KSTEP);
             }
-            pv(sacc, ldsV, kt, true);
             if (kt + 1 < nkt) store_tile(nxt);
             __syncthreads();   // one barrier per tile: the other stage was last read in iteration kt-1
         };
@@ -542,10 +550,13 @@ int launch(const AttnArgs &a, int B, int max_q, bool pre, hipStream_t st) {
         else if constexpr (sizeof(T) == 2) {
             // the training steps' form: two query blocks per wave (ACAI_ATTN_NQ=1: one, A/B aid) when the sequences are long enough to fill the chip
             static const int nq_env = getenv("ACAI_ATTN_NQ") ? atoi(getenv("ACAI_ATTN_NQ")) : 2;
-            if (DHP == 32 && nq_env == 2 && max_q >= 512)   // (d_h = 64: two blocks need more than 256 registers - it spilt 95 of them into the loop)
-                hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, true, false, true, 2>), dim3(cdiv(max_q, 2 * QB), a.H, B), dim3(256), 0, st, a);
-            else
-                hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, true, false, true>), grid, dim3(256), 0, st, a);
+            // (d_h = 64 keeps one block: two need more than 256 registers - 81-95 spilt into the loop, also with one key block at a time)
+            bool two = false;
+            if constexpr (DHP == 32) {
+                two = nq_env == 2 && max_q >= 512;
+                if (two) hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, true, false, true, 2>), dim3(cdiv(max_q, 2 * QB), a.H, B), dim3(256), 0, st, a);
+            }
+            if (!two) hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, true, false, true>), grid, dim3(256), 0, st, a);
         } else
             hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, true, false, true>), grid, dim3(256), 0, st, a);
     } else if (a.drop_thr) {

@@ -270,7 +270,7 @@ def bench_mae(dev, rank, world, dist, batch, height, width, steps, dtype, want_c
                            backward_pair=dict(kernels="attn_bwd_dq_kernel + attn_bwd_dkv_kernel (same layer)", us=b_s * 1e6,
                                               flops_algorithmic=2.5 * k_flops, achieved=2.5 * k_flops / b_s / 1e12,
                                               frac=2.5 * k_flops / b_s / 1e12 / MFMA_PEAK_TFS),
-                           note="VALU-issue bound, not MFMA bound: per score the forward issues one exp2, one add and half a pack (PMC in DESIGN.md section 6)")
+                           note="VALU-issue bound, not MFMA bound: per score the forward issues one exp2 and half a pack, the row sums ride the matrix cores, two query blocks per wave share every fragment read (DESIGN.md section 5)")
     del o, dout, dqkv, lse
     del mae, qkv
     torch.cuda.empty_cache()
