@@ -290,7 +290,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WA
     // compiler keep two copies of O (16 v_mov_b64 per tile behind an s_nop that waits out the last MFMA).
     int n_fast = min(nkt, (a.causal ? min(lk, q0 + 1) : lk) / KT);
     bool bad = false;
-    if (n_fast > 0) {
+    // ZREF (two blocks per wave): the reference "maximum" of the fast loop is ZERO - probabilities are 2^score as they stand, the score
+    // accumulators start at the inline constant 0 instead of a 16-register vector of -m per block (the registers the second block needs at
+    // d_h = 64), and no tile-0 maximum is taken.  fp32 / bf16 hold 2^score for scores in (-126, 127) (log2 domain: +-85 in natural units,
+    // LayerNorm-ed activations stay within a few tens); a row sum beyond 2^100 or below 2^-100 (or inf / NaN) restarts the workgroup in
+    // the general loop like any other overflow.  O / l does not depend on the reference.
+    constexpr bool ZREF = NQ == 2 && PRE && MFSUM;
+    if (ZREF && n_fast > 0) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) m_run[j] = 0.f;
+    } else if (n_fast > 0) {
         f32x16 s0[NQ][2];
 #pragma unroll
         for (int j = 0; j < NQ; ++j)
@@ -314,7 +323,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WA
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) minit[j][e] = PRE ? -m_run[j] : 0.f;
+        for (int e = 0; e < 16; ++e) minit[j][e] = (PRE && !ZREF) ? -m_run[j] : 0.f;
     // A wave whose 32 queries all lie past the end of the sequence (513 decoder tokens: the fifth 128-query block holds ONE row) only helps
     // with the staging: it skips the products and the softmax, which leaves the CU's issue slots to the co-resident workgroups.  Its own loop,
     // so that the working waves' loop stays one basic block.
@@ -387,7 +396,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ACAI_FWD_WA
         for (int j = 0; j < NQ; ++j) {
             const float full = __shfl(lsum[j][0][0] + lsum[j][1][0], (lane & 16) ? 32 + (lane & 15) : (lane & 15));
             if (wave_active && n_fast > 0) {
-                bad |= !(full < 1.2e30f);
+                bad |= !(full < 1.2e30f) || (ZREF && !(full > 1.0e-30f));
                 l_run[j] = lh == 0 ? full : 0.f;
             }
         }
@@ -550,7 +559,7 @@ int launch(const AttnArgs &a, int B, int max_q, bool pre, hipStream_t st) {
         else if constexpr (sizeof(T) == 2) {
             // the training steps' form: two query blocks per wave (ACAI_ATTN_NQ=1: one, A/B aid) when the sequences are long enough to fill the chip
             static const int nq_env = getenv("ACAI_ATTN_NQ") ? atoi(getenv("ACAI_ATTN_NQ")) : 2;
-            // (d_h = 64 keeps one block: two need more than 256 registers - 81-95 spilt into the loop, also with one key block at a time)
+            // (d_h = 64 keeps one block: two need 256 registers + 55 spilt even with the zero reference, and measured 5 % slower - 0.97 against 0.92 ms)
             bool two = false;
             if constexpr (DHP == 32) {
                 two = nq_env == 2 && max_q >= 512;
