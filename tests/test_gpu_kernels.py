@@ -191,6 +191,30 @@ def test_attn_varlen_reference_maximum_restart(dev, dtype, prescaled, causal, le
     assert err < (2e-5 if dtype == "fp32" else 1.2e-2 * max(1.0, float(ref.abs().max()))), err
 
 
+@pytest.mark.parametrize("shift", [-4.0, 4.0])
+def test_attn_varlen_two_block_forward_zero_reference_restart(dev, shift):
+    """The two-blocks-per-wave forward (bf16, q prescaled, d_h = 32, >= 512 queries) takes probabilities as 2^score against a ZERO reference.
+    Rows whose scores ALL sit ~130 below (or above) zero in the log2 domain underflow (overflow) every probability: the row sum leaves
+    (2^-100, 2^100), the workgroup starts over with a running maximum, and the result is the plain softmax."""
+    from acai_omr_amd import engine, ops
+    H, dh, lens = 2, 32, [600, 520]
+    E = H * dh
+    g = torch.Generator().manual_seed(23)
+    q = torch.randn(sum(lens), E, generator=g) * 0.1 + 4.0
+    k = torch.randn(sum(lens), E, generator=g) * 0.05 + shift
+    v = torch.randn(sum(lens), E, generator=g)
+    bf = torch.bfloat16
+    q, k, v = (t.to(bf).float() for t in (q, k, v))
+    qd = (q * ops.QSCALE(dh)).to(bf)
+    cu = engine.cu_from_lens(lens, dev)
+    lse = torch.empty(H * sum(lens), device=dev)
+    out = ops.attn_varlen(qd.to(dev), k.to(dev).to(bf), v.to(dev).to(bf), cu, cu, H, dh, max(lens), lse=lse, q_prescaled=True)
+    ref = ref_attn(qd.double() / ops.QSCALE(dh), k, v, lens, lens, H, dh, False)
+    assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(lse).all())
+    assert (out.cpu().double() - ref).abs().max() < 1.2e-2 * max(1.0, float(ref.abs().max()))
+    assert float(lse.abs().min()) > 100.0        # the scores really are that far from zero
+
+
 def test_patchify_and_gather(dev):
     from acai_omr_amd import ops
     from oracle import vitomr_oracle as O
