@@ -122,6 +122,30 @@ def _wgrad(W, dy, x):
     return _pgrad_note(W, ops.gemm(dy, x, trans_a=True, trans_w=True, out_dtype=torch.float32))
 
 
+def _wgrad_rows(W, r0, r1, dy, x):
+    """Rows [r0, r1) of the gradient of a fused parameter (the q / k-v rows of nn.MultiheadAttention.in_proj_weight): the product lands in its
+    rows of ONE full-size zeroed tensor per backward pass - autograd's slice backward made a zero-filled full tensor, a copy and an add per
+    slice and pass (cross attention: ~100 of each per teacher-forced step)."""
+    prev = _pgrad_prev(W)
+    if prev is None:
+        g = ops._ZEROS.take(W.shape[0], W.shape[1], W.device)
+        _pgrad_note(W, g)
+        ops.gemm(dy, x, trans_a=True, trans_w=True, out=g[r0:r1])
+        return g
+    ops.gemm(dy, x, trans_a=True, trans_w=True, out=prev[r0:r1])
+    return None
+
+
+def _bgrad_rows(b, r0, r1, dy, cs=None):
+    prev = _pgrad_prev(b)
+    g = prev if prev is not None else _pgrad_note(b, ops._ZEROS.take(1, b.shape[0], b.device).view(-1))
+    if cs is not None:
+        g[r0:r1].add_(cs)
+    else:
+        ops.colsum(dy, out=g[r0:r1])
+    return None if prev is not None else g
+
+
 def _bgrad(b, dy, cs=None):
     """db = column sums of dy (cs: already formed by the LayerNorm backward that produced dy)."""
     prev = _pgrad_prev(b)
@@ -143,11 +167,12 @@ class LinearFn(Function):
         """col_scale = (n, s): the first n output columns leave the epilogue multiplied by s (a q projection for attention kernels that take a
         prescaled q; the attention backward returns the gradient w.r.t. the UNSCALED output, so nothing changes below)."""
         bf = prec == "bf16"
-        Wc, bc = wc.w(W, prec), wc.b(b, prec)
+        Wc, bc = wc.w(W, prec), wc.b(b, prec)   # (a _SliceCache hands out its rows of the fused parameter W / b)
         out_dtype = torch.float32 if (residual is not None or out_fp32 or not bf) else torch.bfloat16
         y = ops.gemm_nt(x, Wc, bc, residual=residual, out_dtype=out_dtype, round_bf16=bf, col_scale=col_scale)
         ctx.save_for_backward(x, W, b)
         ctx.prec, ctx.wc, ctx.has_res, ctx.has_bias = prec, wc, residual is not None, b is not None
+        ctx.rows = (wc.r0, wc.r1) if isinstance(wc, _SliceCache) else None
         return y
 
     @staticmethod
@@ -158,8 +183,13 @@ class LinearFn(Function):
         dres = dy if ctx.has_res else None
         dyc, cs = _grad_copy_cs(dy, prec)
         dx = ops.gemm_nt(dyc, ctx.wc.wt(W, prec), out_dtype=x.dtype) if ctx.needs_input_grad[0] else None
-        dW = _wgrad(W, dyc, x) if ctx.needs_input_grad[1] else None
-        db = _bgrad(b, dyc, cs) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        if ctx.rows is not None:
+            r0, r1 = ctx.rows
+            dW = _wgrad_rows(W, r0, r1, dyc, x) if ctx.needs_input_grad[1] else None
+            db = _bgrad_rows(b, r0, r1, dyc, cs) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        else:
+            dW = _wgrad(W, dyc, x) if ctx.needs_input_grad[1] else None
+            db = _bgrad(b, dyc, cs) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dW, db, dres, None, None, None, None
 
 
@@ -907,10 +937,11 @@ def decoder_forward(dec, input_seqs, img_latent, lmx_attention_mask, latent_atte
         x32 = LayerNormFn.apply(y, ly.norm1.weight, ly.norm1.bias, ly.norm1.eps)
         xc = CastBf16Fn.apply(x32) if bf else x32
         pre = _q_prescale(prec, E, dh)
-        q = LinearFn.apply(xc, ca.in_proj_weight[:E], ca.in_proj_bias[:E], None, prec, _SliceCache(wc, ca, 0, E), False, (E, ops.QSCALE(dh)) if pre else None)
+        # (the fused parameters go in whole: LinearFn takes its rows through the _SliceCache and writes their gradient into the full-size tensor)
+        q = LinearFn.apply(xc, ca.in_proj_weight, ca.in_proj_bias, None, prec, _SliceCache(wc, ca, 0, E), False, (E, ops.QSCALE(dh)) if pre else None)
         kv = None if share is None else share["kv"].get(li)
         if kv is None:
-            kv = LinearFn.apply(memc, ca.in_proj_weight[E:], ca.in_proj_bias[E:], None, prec, _SliceCache(wc, ca, E, 3 * E), False)
+            kv = LinearFn.apply(memc, ca.in_proj_weight, ca.in_proj_bias, None, prec, _SliceCache(wc, ca, E, 3 * E), False)
             if share is not None:
                 share["kv"][li] = kv
         a = CrossAttnFn.apply(q, kv, cu_t, cu_s, H, dh, mt, ms, _p_of(ca, tr), pre)
