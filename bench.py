@@ -267,7 +267,7 @@ def bench_mae(dev, rank, world, dist, batch, height, width, steps, dtype, want_c
                            achieved=k_flops / k_s / 1e12, peak=MFMA_PEAK_TFS, unit="TFLOP/s", frac=k_flops / k_s / 1e12 / MFMA_PEAK_TFS,
                            traffic=None, kernel_us=k_s * 1e6, flops_per_launch=k_flops, step_flops=step_flops,
                            step_achieved_TFs=step_flops / (ms * 1e-3) / 1e12, step_frac=step_flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFS,
-                           backward_pair=dict(kernels="attn_bwd_dq_kernel + attn_bwd_dkv_kernel (same layer)", us=b_s * 1e6,
+                           backward_pair=dict(kernels="attn_bwd_dq2_kernel + attn_bwd_dkv2_kernel (same layer; two lane-owned blocks per wave)", us=b_s * 1e6,
                                               flops_algorithmic=2.5 * k_flops, achieved=2.5 * k_flops / b_s / 1e12,
                                               frac=2.5 * k_flops / b_s / 1e12 / MFMA_PEAK_TFS),
                            note="VALU-issue bound, not MFMA bound: per score the forward issues one exp2 and half a pack, the row sums ride the matrix cores, two query blocks per wave share every fragment read (DESIGN.md section 5)")
