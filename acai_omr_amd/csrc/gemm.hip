@@ -558,6 +558,30 @@ __device__ __forceinline__ void glds16s_x4(uint32_t lds_dst, const void *sbase, 
                  : "memory", "scc");
 }
 
+// The same through a buffer resource (buffer_load_dwordx4 ... offen lds): lanes whose offset lies beyond the resource's num_records write
+// ZEROS into LDS (measured, tools/experiments/lds_dma_oob.hip: per dword) - a ragged last K-tile of the token-major operands needs no
+// remainder launch.  (Only the VGPR offset is range-checked, not an SGPR offset: the K-step's advance goes into the resource's base.)
+__device__ __forceinline__ void blds16(uint32_t lds_dst, __amdgpu_buffer_rsrc_t rs, uint32_t voff) {
+    uint32_t m0_save;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_save)
+                 : "s"(lds_dst), "v"(voff), "s"(rs)
+                 : "memory");
+}
+
+__device__ __forceinline__ void blds16_x4(uint32_t lds_dst, __amdgpu_buffer_rsrc_t rs, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3) {
+    uint32_t m0_save;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %6, 0 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %6, 0 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %6, 0 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %6, 0 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(m0_save)
+                 : "s"(lds_dst), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(rs)
+                 : "memory", "scc");
+}
+
 // ---- 256x128 tile, 8 waves, THREE LDS stages (144 KB): two K-tiles in flight ------------------------------------------------------------
 // The two-stage kernels are latency-bound, not MFMA-bound (PMC: MFMA busy 36 %, a third of the wave cycles in s_waitcnt, L2 hit rate 64 %):
 // with one tile in flight per workgroup a CU has 64 KB outstanding, and 64 KB x 256 CUs / ~1.2 us of loaded L2/fabric latency is exactly the
@@ -1811,7 +1835,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
         pid -= kslice * nwg;
     }
     const int bm0 = (pid / nbn) * BMT, bn0 = (pid % nbn) * BN;
-    int nkt = g.K / BKT, kt_begin = 0;
+    int nkt = (g.K + BKT - 1) / BKT, kt_begin = 0;   // the last K-tile may be ragged: its missing token rows arrive as zeros (blds16)
     if (g.ksplit > 1) {
         const int per = (nkt + g.ksplit - 1) / g.ksplit;
         kt_begin = kslice * per;
@@ -1831,25 +1855,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     // LDS-DMA instruction j (0..15) of an image covers token rows 4j .. 4j+3; lane l lands at row 4j + l/16, 16-byte unit l%16, which holds logical
     // unit (l%16) ^ ((row & 3) << 2).  Wave w issues j = 2w, 2w+1 of each of the three images: six instructions per wave and K-tile.
     // Columns beyond M / N are clamped to the last whole chunk (their outputs are never stored).
-    const T *src[6];
+    uint32_t src[6];   // byte offsets from the K-tile's first token row (the host checks that they fit 32 bits)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r = (wave * 2 + i) * 4 + (lane >> 4);
         const int u = (lane & 15) ^ ((r & 3) << 2);
-        src[i] = A + (size_t)r * g.lda + min(bm0 + u * 8, g.M - 8);
-        src[2 + i] = A + (size_t)r * g.lda + min(bm0 + 128 + u * 8, g.M - 8);
-        src[4 + i] = W + (size_t)r * g.ldw + min(bn0 + u * 8, g.N - 8);
+        src[i] = (uint32_t)r * (uint32_t)(g.lda * 2) + (uint32_t)min(bm0 + u * 8, g.M - 8) * 2;
+        src[2 + i] = (uint32_t)r * (uint32_t)(g.lda * 2) + (uint32_t)min(bm0 + 128 + u * 8, g.M - 8) * 2;
+        src[4 + i] = (uint32_t)r * (uint32_t)(g.ldw * 2) + (uint32_t)min(bn0 + u * 8, g.N - 8) * 2;
     }
     typedef __attribute__((address_space(3))) void *lds_ptr;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr)lds;
     auto issue = [&](int kt, int slot) {
         const uint32_t lb = lds_base + slot * STAGE;
+        const int rows = min(g.K - kt * BKT, BKT);   // token rows of this K-tile that exist
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(A + (size_t)kt * BKT * g.lda), 0, rows * g.lda * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(W + (size_t)kt * BKT * g.ldw), 0, rows * g.ldw * 2, 0x00020000);
 #pragma unroll
         for (int m = 0; m < 3; ++m)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const uint32_t dst = __builtin_amdgcn_readfirstlane(lb + m * IMG + (wave * 2 + i) * 1024);
-                glds16(dst, src[2 * m + i] + (size_t)kt * BKT * (m == 2 ? g.ldw : g.lda));
+                blds16(dst, m == 2 ? rw : ra, src[2 * m + i]);
             }
     };
     typedef __attribute__((ext_vector_type(4))) short s4;
@@ -1922,7 +1949,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
         pid -= kslice * nwg;
     }
     const int bm0 = (pid / nbn) * BT, bn0 = (pid % nbn) * BT;
-    int nkt = g.K / BKT, kt_begin = 0;
+    int nkt = (g.K + BKT - 1) / BKT, kt_begin = 0;   // the last K-step may be ragged: its missing token rows arrive as zeros (blds16_x4)
     if (g.ksplit > 1) {
         const int per = (nkt + g.ksplit - 1) / g.ksplit;
         kt_begin = kslice * per;
@@ -1932,6 +1959,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     const int total = nkt - kt_begin;
     const T *A = reinterpret_cast<const T *>(g.A) + (size_t)kt_begin * BKT * g.lda;
     const T *W = reinterpret_cast<const T *>(g.W) + (size_t)kt_begin * BKT * g.ldw;
+    const int rows_left0 = g.K - kt_begin * BKT;   // token rows from this slice's first K-step to the end of the operands
     typedef __attribute__((address_space(3))) void *lds_ptr;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr)lds;
 
@@ -1951,13 +1979,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     auto next_slot = [&]() { p_slot = p_slot == NSLOT - 1 ? 0 : p_slot + 1; };
     auto issue_a = [&]() {
         if (a_done >= total) return;
-        glds16s_x4(__builtin_amdgcn_readfirstlane(lds_base + p_slot * UNIT + wave * 4096), A + (size_t)a_done * BKT * g.lda, offA[0], offA[1], offA[2], offA[3]);
+        blds16_x4(__builtin_amdgcn_readfirstlane(lds_base + p_slot * UNIT + wave * 4096),
+                  __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(A + (size_t)a_done * BKT * g.lda), 0, min(rows_left0 - a_done * BKT, BKT) * g.lda * 2, 0x00020000),
+                  offA[0], offA[1], offA[2], offA[3]);
         ++a_done;
         next_slot();
     };
     auto issue_w = [&]() {
         if (w_done >= total) return;
-        glds16s_x4(__builtin_amdgcn_readfirstlane(lds_base + p_slot * UNIT + wave * 4096), W + (size_t)w_done * BKT * g.ldw, offW[0], offW[1], offW[2], offW[3]);
+        blds16_x4(__builtin_amdgcn_readfirstlane(lds_base + p_slot * UNIT + wave * 4096),
+                  __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(W + (size_t)w_done * BKT * g.ldw), 0, min(rows_left0 - w_done * BKT, BKT) * g.ldw * 2, 0x00020000),
+                  offW[0], offW[1], offW[2], offW[3]);
         ++w_done;
         next_slot();
     };
@@ -2110,12 +2142,15 @@ int launch(const GemmArgs &g, hipStream_t st) {
         if (fast && !no_tn && !no_glds && h.ksplit > 0 && g.K >= 64 && g.M % 8 == 0 && g.N % 8 == 0 && g.M >= 8 && g.N >= 8) {
             // token counts that are not a multiple of 64 (16 x 513 decoder tokens): the LDS-DMA kernel takes the whole 64-token tiles, the
             // register-staged kernel accumulates the remaining rows into the same gradient
+            // (round 3: the ring and ping-pong kernels take the ragged last tile themselves - out-of-range rows of a buffer LDS-DMA arrive as
+            // zeros; only the two-stage kernel still leaves the remainder to the register-staged one)
             const int k64 = g.K - g.K % 64;
             GemmArgs m = h;
             m.K = k64;
+            bool whole = false;   // the launched kernel covered every token row
             // the three-stage ring (256 x 128 tiles, one workgroup per CU) when the reduction is long enough to fill it: split K until ~256 workgroups exist
             static const bool no_ring = getenv("ACAI_GEMM_TN_RING") && atoi(getenv("ACAI_GEMM_TN_RING")) == 0;   // A/B aid
-            const int tiles_r = cdiv(g.M, 256) * cdiv(g.N, BN), nkt_r = k64 / 64;
+            const int tiles_r = cdiv(g.M, 256) * cdiv(g.N, BN), nkt_r = cdiv(g.K, 64);
             int ks_r = 256 / tiles_r;            // one resident workgroup per CU: never more workgroups than CUs (a second, nearly empty round doubles the time)
             if (ks_r < 1) ks_r = 1;
             if (ks_r > nkt_r / 8) ks_r = nkt_r / 8;
@@ -2130,13 +2165,17 @@ int launch(const GemmArgs &g, hipStream_t st) {
             // splits cost more than the main loop gains - encoder dWo, 768 x 768 from 32768 tokens: 82 us on the ring, 89 us here)
             if (tn_pp && !no_ring && ks_p >= 1 && nkt_r >= 16 && pp_fits && nkt_r / ks_p >= 24) {
                 m.ksplit = ks_p;
+                m.K = g.K;
+                whole = true;
                 hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3(tiles_p * ks_p), dim3(512), 0, st, m);
-            } else if (!no_ring && ks_r >= 1 && nkt_r >= 16) {
+            } else if (!no_ring && ks_r >= 1 && nkt_r >= 16 && pp_fits) {
                 m.ksplit = ks_r;
+                m.K = g.K;
+                whole = true;
                 hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3(tiles_r * ks_r), dim3(512), 0, st, m);
             } else
             hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(nwg), dim3(256), 0, st, m);
-            if (k64 < g.K) {
+            if (k64 < g.K && !whole) {
                 GemmArgs t = h;
                 t.A = reinterpret_cast<const T *>(g.A) + (size_t)k64 * g.lda;
                 t.W = reinterpret_cast<const T *>(g.W) + (size_t)k64 * g.ldw;

@@ -463,7 +463,10 @@ def test_gemm_nt_pingpong_deferred_gelu(dev, shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(3072, 512, 16384), (520, 264, 8192 + 40), (768, 2304, 4096), (512, 512, 32768)])
+@pytest.mark.parametrize("shape", [(3072, 512, 16384), (520, 264, 8192 + 40), (768, 2304, 4096), (512, 512, 32768),
+                                   # 16 x 513 decoder tokens = 128 whole 64-token tiles + 16 rows: the ragged tile inside the ring (1024 x 1024) and the
+                                   # ping-pong (4096 x 1024) kernel - rows beyond the end arrive as zeros through the buffer LDS-DMA
+                                   (1024, 1024, 8208), (4096, 1024, 8208), (1024, 4096, 8208 + 63), (2048, 1024, 1024 + 1)])
 def test_gemm_weight_gradient_pingpong(dev, shape):
     """dW = dY^T X on the ping-pong TN kernel (gemm_tn_pp_kernel: 256 x 256 tiles, transposing fragment reads out of the swizzled natural
     image, split-K atomics from the 16x16 accumulators), long token counts incl. a ragged last 64-token tile, ragged output edges."""
