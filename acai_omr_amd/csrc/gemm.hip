@@ -33,6 +33,8 @@ struct GemmArgs {
     // columns [0, scale_cols) of (A.W^T + bias) are multiplied by col_scale before rounding (the in-projection's q for the attention kernels)
     int scale_cols;
     float col_scale;
+    // dW form (TA && TB): also accumulate the column sums of the token-major A operand (= the bias gradient next to dW = dY^T X) into colsum[M]
+    float *colsum;
     // EPI == 1 (cross K/V prefill scatter)
     const int32_t *row_seq, *row_pos, *seq_len;
     const int64_t *seq_off;
@@ -2029,12 +2031,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
         for (int i = 0; i < 8; ++i) fa[i] = frag(sa + wm * IMG, i * 16, kh);
     };
+    // Bias gradient beside the weight gradient (g.colsum): the column sums of dY are one more product of the dY fragments already in registers,
+    // against a B operand of ones.  The 16-column fragments of a 128-column group are dealt over the tile columns (workgroups bn) and the four
+    // waves that share them: fragment i belongs to the workgroup with bn % nbn == i % nbn and its wave wn == (i / nbn) % 4, slot i / (4 nbn) -
+    // at most two extra MFMAs per 32 and wave (one from nbn = 2 on), instead of a separate pass over dY (colsum_vec_kernel: 1.9 ms per MAE step).
+    const bool do_cs = g.colsum != nullptr;
+    const int cs_b = pid % nbn;
+    f32x4 csacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const uint4 ones8 = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+    auto cs_mine = [&](int i) -> bool { return (i % nbn) == cs_b && ((i / nbn) & 3) == wn && i / (4 * nbn) < 2; };
     auto mfmas = [&]() {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fw[j]), acc[i][j], 0, 0, 0);
+        if (do_cs) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (cs_mine(i)) {   // (wave-uniform)
+                    if (i / (4 * nbn) == 0) csacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, ones8), csacc[0], 0, 0, 0);
+                    else csacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, ones8), csacc[1], 0, 0, 0);
+                }
+        }
     };
 #define PP_BAR()                                      \
     do {                                              \
@@ -2087,6 +2106,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     if (grp == 0) PP_BAR();
 #undef PP_BAR
 #undef PP_LGKM0
+    if (do_cs && (lane & 15) == 0) {   // every column n of the 16x16 result holds the same sums: lanes with n = 0 add rows 4 lq .. 4 lq + 3
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (cs_mine(i)) {
+                const f32x4 v = i / (4 * nbn) == 0 ? csacc[0] : csacc[1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = bm0 + wm * 128 + i * 16 + 4 * lq + e;
+                    if (m < g.M) atomicAdd(g.colsum + m, v[e]);
+                }
+            }
+    }
     // ---- split-K accumulation: four 64-byte row segments per wave instruction ----
     const int m0 = bm0 + wm * 128 + 4 * lq, n0 = bn0 + wn * 64 + (lane & 15);
 #pragma unroll
@@ -2115,6 +2146,7 @@ static inline bool pp_mode_ok(int m) {
 }
 
 int g_gemm_variant = getenv("ACAI_GEMM_VARIANT") ? atoi(getenv("ACAI_GEMM_VARIANT")) : 0;
+int g_tn_colsum_done = 0;   // set by the dW dispatch when the launched kernel also formed the column sums (acai_gemm_dw: else a separate pass)
 
 template <typename T, int EPI, bool TA = false, bool TB = false>
 int launch(const GemmArgs &g, hipStream_t st) {
@@ -2163,9 +2195,13 @@ int launch(const GemmArgs &g, hipStream_t st) {
             const bool pp_fits = (size_t)64 * g.lda * 2 + (size_t)g.M * 2 < 0xFFFFFF00ull && (size_t)64 * g.ldw * 2 + (size_t)g.N * 2 < 0xFFFFFF00ull;
             // (short K-slices keep the 256 x 128 ring: with fewer than ~24 K-steps per workgroup the atomics of the larger tile's extra
             // splits cost more than the main loop gains - encoder dWo, 768 x 768 from 32768 tokens: 82 us on the ring, 89 us here)
+            float *const want_cs = g.colsum;   // only the ping-pong kernel forms the column sums itself
+            m.colsum = nullptr;
             if (tn_pp && !no_ring && ks_p >= 1 && nkt_r >= 16 && pp_fits && nkt_r / ks_p >= 24) {
                 m.ksplit = ks_p;
                 m.K = g.K;
+                m.colsum = want_cs;
+                g_tn_colsum_done = want_cs != nullptr;
                 whole = true;
                 hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3(tiles_p * ks_p), dim3(512), 0, st, m);
             } else if (!no_ring && ks_r >= 1 && nkt_r >= 16 && pp_fits) {
@@ -2363,6 +2399,25 @@ extern "C" int acai_gemm(const void *A, int lda, int trans_a, const void *W, int
         case 2: return launch<float, 0, true, false>(g, st);
         default: return launch<float, 0, true, true>(g, st);
     }
+}
+
+// dW[M][N] += dY^T X and, optionally, db[M] += column sums of dY: the two parameter gradients of an nn.Linear from one pass over dY
+// (autograd of F.linear, models.py:29,57,...; torch computes them as mm + sum).  bf16 operands [K tokens][.], fp32 accumulators (zero them for
+// fresh gradients).  The ping-pong weight-gradient kernel forms the sums from the dY fragments it holds; other shapes take acai_colsum.
+extern "C" int acai_gemm_dw(const void *dY, int ldy, const void *X, int ldx, float *dW, int lddw, float *db, int M, int N, int K, int dtype, void *stream) {
+    ACAI_CHECK_ARG(dY && X && dW, "acai_gemm_dw: null operand");
+    ACAI_CHECK_ARG(M > 0 && N > 0 && K > 0 && ldy >= M && ldx >= N && lddw >= N, "acai_gemm_dw: bad shape M=%d N=%d K=%d", M, N, K);
+    ACAI_CHECK_ARG(dtype == ACAI_F32 || dtype == ACAI_BF16, "acai_gemm_dw: bad dtype");
+    GemmArgs g{};
+    g.A = dY; g.W = X; g.C = dW; g.lda = ldy; g.ldw = ldx; g.ldc = lddw; g.M = M; g.N = N; g.K = K;
+    g.out_dtype = ACAI_F32;
+    g.colsum = dtype == ACAI_BF16 ? db : nullptr;
+    g_tn_colsum_done = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = dtype == ACAI_BF16 ? launch<bf16_t, 0, true, true>(g, st) : launch<float, 0, true, true>(g, st);
+    if (rc) return rc;
+    if (db && !g_tn_colsum_done) return acai_colsum(dY, ldy, db, K, M, dtype, stream);
+    return 0;
 }
 
 extern "C" int acai_cross_kv_prefill(const void *mem, int ldm, const void *Wkv, int ldw, const float *bkv, const int32_t *row_seq,

@@ -385,6 +385,26 @@ def layernorm_bwd(x, w, dy, eps, want_param_grads=True, want_bf16=False, want_co
     return out + (dcs,) if want_colsum else out
 
 
+def gemm_dw(dy, x, out=None, bias_out=None, want_bias=False):
+    """Both parameter gradients of an nn.Linear from one pass over dy: dW[M, N] (+)= dy[K, M]^T x[K, N] and, with want_bias or bias_out,
+    db[M] (+)= column sums of dy.  out / bias_out: existing fp32 gradients to ACCUMULATE into (else zeroed arena slices).  Returns (dW, db)."""
+    _chk(dy, "dy"), _chk(x, "x")
+    assert dy.dim() == 2 and x.dim() == 2 and dy.dtype == x.dtype and dy.shape[0] == x.shape[0] and dy.stride(1) == 1 and x.stride(1) == 1
+    K, M = dy.shape
+    N = x.shape[1]
+    if out is None:
+        out = _ZEROS.take(M, N, dy.device)
+    if bias_out is None and want_bias:
+        bias_out = _ZEROS.take(1, M, dy.device).view(-1)
+    assert out.shape == (M, N) and out.dtype == torch.float32 and out.stride(1) == 1
+    if bias_out is not None:
+        _chk(bias_out, "bias_out", torch.float32)
+        assert bias_out.is_contiguous() and bias_out.numel() == M
+    _lib.check(_lib.lib().acai_gemm_dw(dy.data_ptr(), _ld(dy), x.data_ptr(), _ld(x), out.data_ptr(), _ld(out), _p(bias_out), M, N, K, _dt(dy), _st()),
+               "acai_gemm_dw")
+    return out, bias_out
+
+
 def cast_weights(items):
     """One launch for the operand copies of many fp32 parameters (engine.WeightCache after an optimizer step).  items: (src, want16, want16t,
     want32r) with src a contiguous fp32 CUDA tensor of one or two dimensions; returns per item (bf16 copy | None, transposed bf16 copy

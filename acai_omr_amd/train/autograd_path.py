@@ -122,6 +122,21 @@ def _wgrad(W, dy, x):
     return _pgrad_note(W, ops.gemm(dy, x, trans_a=True, trans_w=True, out_dtype=torch.float32))
 
 
+def _wbgrad(W, b, dy, x, cs, need_w, need_b):
+    """(dW, db) of an nn.Linear.  When both are wanted and nobody formed the column sums yet (cs), ONE launch reads dy once for both
+    (ops.gemm_dw: the weight-gradient kernel sums its dy fragments on the side) instead of a GEMM plus a column-sum pass over dy."""
+    need_b = need_b and b is not None
+    if not (need_w and need_b and cs is None and dy.dtype == torch.bfloat16):
+        return (_wgrad(W, dy, x) if need_w else None), (_bgrad(b, dy, cs) if need_b else None)
+    pw, pb = _pgrad_prev(W), _pgrad_prev(b)
+    if (pw is None) != (pb is None):
+        return _wgrad(W, dy, x), _bgrad(b, dy, cs)
+    gw, gb = ops.gemm_dw(dy, x, out=pw, bias_out=pb, want_bias=True)
+    if pw is None:
+        return _pgrad_note(W, gw), _pgrad_note(b, gb)
+    return None, None
+
+
 def _wgrad_rows(W, r0, r1, dy, x):
     """Rows [r0, r1) of the gradient of a fused parameter (the q / k-v rows of nn.MultiheadAttention.in_proj_weight): the product lands in its
     rows of ONE full-size zeroed tensor per backward pass - autograd's slice backward made a zero-filled full tensor, a copy and an add per
@@ -188,8 +203,7 @@ class LinearFn(Function):
             dW = _wgrad_rows(W, r0, r1, dyc, x) if ctx.needs_input_grad[1] else None
             db = _bgrad_rows(b, r0, r1, dyc, cs) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         else:
-            dW = _wgrad(W, dyc, x) if ctx.needs_input_grad[1] else None
-            db = _bgrad(b, dyc, cs) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            dW, db = _wbgrad(W, b, dyc, x, cs, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
         return dx, dW, db, dres, None, None, None, None
 
 
@@ -245,13 +259,11 @@ class MlpFn(Function):
         dy = dy.contiguous()
         dyc, cs = _grad_copy_cs(dy, prec)
         da = ops.gemm_nt(dyc, wc.wt(W2, prec), out_dtype=a.dtype, round_bf16=bf, gelu_grad_of=a)     # (dY . W2) o gelu'(a)
-        dW2 = _wgrad(W2, dyc, h) if ctx.needs_input_grad[3] else None
-        db2 = _bgrad(b2, dyc, cs) if ctx.needs_input_grad[4] else None
+        dW2, db2 = _wbgrad(W2, b2, dyc, h, cs, ctx.needs_input_grad[3], ctx.needs_input_grad[4])
         dx = None
         if ctx.needs_input_grad[0]:   # branch gradient (rounded to the compute dtype as the unfused path does) + residual gradient, fp32
             dx = ops.gemm_nt(da, wc.wt(W1, prec), residual=dy.float() if dy.dtype != torch.float32 else dy, out_dtype=torch.float32, round_bf16=bf)
-        dW1 = _wgrad(W1, da, x) if ctx.needs_input_grad[1] else None
-        db1 = _bgrad(b1, da) if ctx.needs_input_grad[2] else None
+        dW1, db1 = _wbgrad(W1, b1, da, x, None, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return dx, dW1, db1, dW2, db2, None, None
 
 
@@ -286,16 +298,14 @@ class SelfAttnBlockFn(Function):
         dy = dy.contiguous()
         dyc, cs = _grad_copy_cs(dy, prec)
         dattn = ops.gemm_nt(dyc, wc.wt(Wo, prec), out_dtype=attn.dtype, round_bf16=bf)
-        dWo = _wgrad(Wo, dyc, attn) if ctx.needs_input_grad[3] else None
-        dbo = _bgrad(bo, dyc, cs) if ctx.needs_input_grad[4] else None
+        dWo, dbo = _wbgrad(Wo, bo, dyc, attn, cs, ctx.needs_input_grad[3], ctx.needs_input_grad[4])
         dqkv = torch.empty_like(qkv)
         ops.attn_varlen_bwd(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], attn, dattn, lse, cu, cu, H, dh, max_len, max_len, causal,
                             dqkv[:, :E], dqkv[:, E:2 * E], dqkv[:, 2 * E:], q_prescaled=pre)   # dq: w.r.t. the UNSCALED in-projection output
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_nt(dqkv, wc.wt(Wi, prec), residual=dy.float() if dy.dtype != torch.float32 else dy, out_dtype=torch.float32, round_bf16=bf)
-        dWi = _wgrad(Wi, dqkv, x) if ctx.needs_input_grad[1] else None
-        dbi = _bgrad(bi, dqkv) if ctx.needs_input_grad[2] else None
+        dWi, dbi = _wbgrad(Wi, bi, dqkv, x, None, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return dx, dWi, dbi, dWo, dbo, None, None, None, None, None, None
 
 

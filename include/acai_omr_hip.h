@@ -66,6 +66,10 @@ int acai_gemm_set_variant(int variant);
  * (split-K over workgroups); zero it for a fresh gradient.  No bias / residual / flags in that form. */
 int acai_gemm(const void *A, int lda, int trans_a, const void *W, int ldw, int trans_w, const float *bias, const float *residual, int ldr,
               void *C, int ldc, int M, int N, int K, int in_dtype, int out_dtype, int flags, void *stream);
+/* Both parameter gradients of an nn.Linear from one pass over the output gradient (autograd of F.linear: torch's mm + sum):
+ * dW[M][N] += dY[K][M]^T X[K][N] and, if db != NULL, db[M] += sum over the K token rows of dY.  fp32 accumulators (zero them for fresh
+ * gradients), bf16 or fp32 operands.  M = out_features, N = in_features, K = token rows. */
+int acai_gemm_dw(const void *dY, int ldy, const void *X, int ldx, float *dW, int lddw, float *db, int M, int N, int K, int dtype, void *stream);
 
 /* MemoryCache.cache_memory_keys_and_vals (K:235-253): KV = mem . W_kv^T + b_kv with W_kv = rows E..3E of the
  * cross-attention in_proj; written head-major and ragged for the decode kernels:

@@ -539,3 +539,28 @@ def test_weight_cache_refreshes_all_stale_copies_together(dev):
     for old, kept in zip(before, keep):
         assert all(torch.equal(a, b) for a, b in zip(old, kept))
     assert all(a is b for a, b in zip(before[2], after[2]))      # the untouched layer's copies are the same tensors
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3072, 512, 16384), (1536, 512, 8192), (768, 768, 32768), (520, 264, 8192 + 40), (4096, 1024, 8208), (1024, 1024, 8208),
+                                   (96, 40, 300)])
+def test_gemm_dw_with_bias_gradient(dev, shape):
+    """acai_gemm_dw: dW = dY^T X and db = column sums of dY from one launch - the ping-pong weight-gradient kernel sums its dY fragments with a
+    ones operand (every tile-column count nbn = 1, 2, 4, 6; ragged token tiles and edges), other shapes take the separate column-sum pass -
+    and accumulation into existing gradients."""
+    from acai_omr_amd import ops
+    M, N, K = shape     # dW is [M, N], K tokens
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    dy = torch.randn(K, M, generator=g).to(torch.bfloat16)
+    x = (torch.randn(K, N, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    ref_w = dy.float().double().t() @ x.float().double()
+    ref_b = dy.float().double().sum(0)
+    dw, db = ops.gemm_dw(dy.to(dev), x.to(dev), want_bias=True)
+    assert (dw.cpu().double() - ref_w).abs().max() < 2e-3 * float(ref_w.abs().max()) + 1e-4
+    assert (db.cpu().double() - ref_b).abs().max() < 2e-3 * float(ref_b.abs().max()) + 1e-3
+    dw2, db2 = ops.gemm_dw(dy.to(dev), x.to(dev), out=dw, bias_out=db)      # accumulate on top
+    assert dw2 is dw and db2 is db
+    assert (dw.cpu().double() - 2 * ref_w).abs().max() < 4e-3 * float(ref_w.abs().max()) + 2e-4
+    assert (db.cpu().double() - 2 * ref_b).abs().max() < 4e-3 * float(ref_b.abs().max()) + 2e-3
+    dw3, none = ops.gemm_dw(dy.to(dev), x.to(dev))                            # weight gradient alone
+    assert none is None and (dw3.cpu().double() - ref_w).abs().max() < 2e-3 * float(ref_w.abs().max()) + 1e-4
