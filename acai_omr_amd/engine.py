@@ -103,10 +103,23 @@ class WeightCache:
         return self._get(p, "b16", lambda t: t.to(torch.bfloat16).to(torch.float32).contiguous())
 
 
+_CU_CACHE = {}
+
+
 def cu_from_lens(lens, device):
+    """int32 cu_seqlens of a packed stream on the device.  Cached per (lengths, device) - a training loop asks for the same few every step -
+    and uploaded without a host stall (ops.h2d).  The tensors are read-only for every consumer."""
+    key = (tuple(int(l) for l in lens), str(device))
+    hit = _CU_CACHE.get(key)
+    if hit is not None:
+        return hit
     cu = torch.zeros(len(lens) + 1, dtype=torch.int32)
-    cu[1:] = torch.tensor(lens, dtype=torch.int32).cumsum(0)
-    return cu.to(device)
+    cu[1:] = torch.tensor(key[0], dtype=torch.int32).cumsum(0)
+    out = ops.h2d(cu, device)
+    if len(_CU_CACHE) >= 256:
+        _CU_CACHE.clear()
+    _CU_CACHE[key] = out
+    return out
 
 
 def linear(x32, xb, lin_w, lin_b, prec, wc, residual=None, gelu=False, out_dtype=None):

@@ -116,6 +116,18 @@ def gemm_nt(a, w, bias=None, residual=None, out_dtype=torch.float32, gelu=False,
     return out
 
 
+def h2d(t, device, dtype=None):
+    """Host tensor -> device WITHOUT stalling the host: staged in pinned memory (torch's caching host allocator) and copied asynchronously on
+    the current stream.  `t.to(device)` from pageable memory synchronises the stream - inside a training step every such copy (cu_seqlens,
+    index lists, optimizer tables) drained the GPU queue and left it idle until the host had enqueued the next kernels (MAE step: 6-9 ms of
+    idle GPU per 120 ms step, tools/gpu_idle_from_trace.py).  Device tensors pass through."""
+    if t.device.type == "cpu" and torch.device(device).type == "cuda":
+        t = t.pin_memory().to(device, non_blocking=True)
+    else:
+        t = t.to(device)
+    return t if dtype is None or t.dtype == dtype else t.to(dtype)
+
+
 class _ZeroArena:
     """Zeroed fp32 scratch for the split-K weight-gradient GEMMs (they accumulate with float atomics into a zeroed output): slices of a few
     large chunks, each zeroed by ONE fill, instead of one `torch.zeros` launch per weight gradient (the MAE step issued ~380 five-microsecond
@@ -425,7 +437,7 @@ def cast_weights(items):
         arr[i].rows, arr[i].cols, arr[i].tile0 = rows, cols, tiles
         tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
         outs.append((d16, d16t, d32))
-    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    table = h2d(torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8), dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().acai_cast_weights(table.data_ptr(), len(items), tiles, _st()), "acai_cast_weights")
     return outs

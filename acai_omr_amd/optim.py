@@ -10,7 +10,7 @@ import math
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 
 CHUNK = 16384  # elements per workgroup
 
@@ -70,14 +70,14 @@ class FusedAdamW(torch.optim.Optimizer):
             arr[i].n, arr[i].group = p.numel(), gi
             b1, b2 = self.param_groups[gi]["betas"]
             arr[i].bias_c1, arr[i].bias_c2_sqrt = 1.0 - b1 ** steps[i], math.sqrt(1.0 - b2 ** steps[i])
-        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        raw = ops.h2d(torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8), dev)
         if self._layout is None or self._layout[0] != key:
             ct, co = [], []
             for i, (gi, p, st) in enumerate(active):
                 for off in range(0, p.numel(), CHUNK):
                     ct.append(i)
                     co.append(off)
-            self._layout = (key, torch.tensor(ct, dtype=torch.int32).to(dev), torch.tensor(co, dtype=torch.int64).to(dev), len(ct))
+            self._layout = (key, ops.h2d(torch.tensor(ct, dtype=torch.int32), dev), ops.h2d(torch.tensor(co, dtype=torch.int64), dev), len(ct))
         return raw, self._layout[1], self._layout[2], self._layout[3]
 
     # ---- step ---------------------------------------------------------------------------------------------------------------------------
@@ -100,7 +100,7 @@ class FusedAdamW(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             garr[gi].lr, garr[gi].beta1, garr[gi].beta2, garr[gi].eps = float(group["lr"]), b1, b2, group["eps"]
             garr[gi].weight_decay = group["weight_decay"]
-        gdev = torch.frombuffer(bytearray(bytes(garr)), dtype=torch.uint8).to(dev)
+        gdev = ops.h2d(torch.frombuffer(bytearray(bytes(garr)), dtype=torch.uint8), dev)
         tdev, ctd, cod, n_chunks = self._build(active, dev, steps)
         with torch.cuda.device(dev):
             st_ = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -96,6 +96,7 @@ def _side_take(t):
 # id: a tensor of an earlier backward pass is never touched.  Weak references: nothing is kept alive.
 _PGRAD = {}
 PGRAD_FUSE = os.environ.get("ACAI_PGRAD_FUSE", "1") != "0"   # A/B and test aid
+_ROWS_DW_FUSE = os.environ.get("ACAI_ROWS_DW_FUSE", "1") != "0"   # A/B aid
 
 
 def _pgrad_prev(param):
@@ -200,8 +201,17 @@ class LinearFn(Function):
         dx = ops.gemm_nt(dyc, ctx.wc.wt(W, prec), out_dtype=x.dtype) if ctx.needs_input_grad[0] else None
         if ctx.rows is not None:
             r0, r1 = ctx.rows
-            dW = _wgrad_rows(W, r0, r1, dyc, x) if ctx.needs_input_grad[1] else None
-            db = _bgrad_rows(b, r0, r1, dyc, cs) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+            if _ROWS_DW_FUSE and need_w and need_b and cs is None and dyc.dtype == torch.bfloat16:
+                # both gradients' rows from one pass over dy (ops.gemm_dw), into the full-size tensors of this backward pass
+                pw, pb = _pgrad_prev(W), _pgrad_prev(b)
+                gw = pw if pw is not None else _pgrad_note(W, ops._ZEROS.take(W.shape[0], W.shape[1], W.device))
+                gb = pb if pb is not None else _pgrad_note(b, ops._ZEROS.take(1, b.shape[0], b.device).view(-1))
+                ops.gemm_dw(dyc, x, out=gw[r0:r1], bias_out=gb[r0:r1])
+                dW, db = (None if pw is not None else gw), (None if pb is not None else gb)
+            else:
+                dW = _wgrad_rows(W, r0, r1, dyc, x) if need_w else None
+                db = _bgrad_rows(b, r0, r1, dyc, cs) if need_b else None
         else:
             dW, db = _wbgrad(W, b, dyc, x, cs, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
         return dx, dW, db, dres, None, None, None, None
@@ -531,8 +541,8 @@ def pad_rows(packed, lens, fill_row=None):
         idx[b, :l] = torch.arange(o, o + l, dtype=torch.int32)
         mask[b, :l] = False
         o += l
-    out = GatherRowsFn.apply(table, idx.reshape(-1).to(dev), None)
-    return out.view(B, Lm, E), mask.to(dev)
+    out = GatherRowsFn.apply(table, ops.h2d(idx.reshape(-1), dev), None)
+    return out.view(B, Lm, E), ops.h2d(mask, dev)
 
 
 def unpad_rows(padded, mask):
@@ -595,7 +605,7 @@ def _patches(enc, imgs, prec, select=None):
         if select is not None:
             o, rows = 0, []
             for l, s in zip(lens, select):
-                rows.append(s.to(dev).to(torch.int32) + o)
+                rows.append(ops.h2d(s, dev, torch.int32) + o)
                 o += l
             patches = ops.gather_rows(patches, torch.cat(rows).contiguous())
         if prec == "bf16":
@@ -611,7 +621,7 @@ def _grid_rows(h_p, w_p, Wm, dev):
     key = (h_p, w_p, Wm, str(dev))
     t = _GRID_ROWS.get(key)
     if t is None:
-        t = (torch.arange(h_p, dtype=torch.int32).unsqueeze(1) * Wm + torch.arange(w_p, dtype=torch.int32).unsqueeze(0)).reshape(-1).to(dev)
+        t = ops.h2d((torch.arange(h_p, dtype=torch.int32).unsqueeze(1) * Wm + torch.arange(w_p, dtype=torch.int32).unsqueeze(0)).reshape(-1), dev)
         if len(_GRID_ROWS) < 256:
             _GRID_ROWS[key] = t
     return t
@@ -635,7 +645,7 @@ def _pe_rows(enc, table_param, dims, select=None):
         else:
             rows = _grid_rows(h_p, w_p, Wm, dev)
         if select is not None:
-            rows = rows[select[i].to(dev)]   # device gather: no host round trip per image
+            rows = rows[ops.h2d(select[i], dev)]   # device gather: no host round trip per image
         idx.append(rows)
     table = table_param.reshape(-1, E)
     if extra:
@@ -698,7 +708,7 @@ def _mae_prepare(mae, x, noises):
         if noises is None:
             noise = torch.rand(len(members), n, device=dev)
         else:
-            noise = torch.stack([noises[i].to(dev).reshape(n) for i in members])
+            noise = torch.stack([ops.h2d(noises[i], dev).reshape(n) for i in members])
         ids_shuffle = torch.argsort(noise, dim=1)
         ids_restore = torch.argsort(ids_shuffle, dim=1)
         seq_mask = (ids_restore >= k).to(torch.int)          # = ones with [:k] zeroed, gathered by ids_restore
@@ -796,9 +806,9 @@ def mae_prepare_for_decoder(mae, latent, kept_seq_lens, unmasked_seq_lens, batch
     lens = [int(n) for n in unmasked_seq_lens]
     latent = latent.to(device=dev, dtype=torch.float32)
     Lk = latent.shape[1]
-    rows = torch.cat([torch.arange(b * Lk, b * Lk + k, dtype=torch.int32) for b, k in enumerate(kept)]).to(dev)
+    rows = ops.h2d(torch.cat([torch.arange(b * Lk, b * Lk + k, dtype=torch.int32) for b, k in enumerate(kept)]), dev)
     lat = GatherRowsFn.apply(latent.reshape(B * Lk, -1), rows, None)          # remove padding (models.py:225)
-    restore = [batch_ids_restore[i].to(dev) for i in range(B)]
+    restore = [ops.h2d(batch_ids_restore[i], dev) for i in range(B)]
     x32 = _restore_rows(mae, lat, kept, lens, restore, [tuple(d) for d in patchified_dims])
     return pad_rows(x32, lens)[0]
 
@@ -834,7 +844,7 @@ def mae_forward(mae, batch, noises=None, packed=False):
     with torch.no_grad():
         timgs = _as_image_list(list(ys), dev)
         target = _patches(mae.encoder, timgs, "fp32")[0]
-        loss_mask = torch.cat([m.to(dev).bool() for m in smask])
+        loss_mask = torch.cat([ops.h2d(m, dev).bool() for m in smask])
     if packed:
         return pred, loss_mask, target, lens
     ppred, pmask = pad_rows(pred, lens)
@@ -887,7 +897,7 @@ def ce_loss(pred, target_seqs, pad_idx, label_smoothing=0.0):
     """OMRCELoss.forward (models.py:784-796): mean CE over non-pad targets, nn.CrossEntropyLoss's label smoothing."""
     V = pred.shape[-1]
     lg = pred.reshape(-1, V).float().contiguous()
-    tg = target_seqs.reshape(-1).to(device=lg.device, dtype=torch.int64).contiguous()
+    tg = ops.h2d(target_seqs.reshape(-1), lg.device, torch.int64).contiguous()
     count = float((tg != pad_idx).sum().item())
     return CeLossFn.apply(lg, tg, pad_idx, count, float(label_smoothing))
 
@@ -927,13 +937,13 @@ def decoder_forward(dec, input_seqs, img_latent, lmx_attention_mask, latent_atte
     else:
         mem32, lens_s = unpad_rows(img_latent.to(dev), latent_attention_mask)
         memc_shared = None
-    pos_idx = torch.cat([torch.arange(t, dtype=torch.int32) for t in lens_t]).to(dev)
+    pos_idx = ops.h2d(torch.cat([torch.arange(t, dtype=torch.int32) for t in lens_t]), dev)
     pos = GatherRowsFn.apply(dec.pos_embedding, pos_idx, None)
     if token_idxs_input:
-        tok = torch.cat([input_seqs[b, :l] for b, l in enumerate(lens_t)]).to(device=dev, dtype=torch.int32).contiguous()
+        tok = ops.h2d(torch.cat([input_seqs[b, :l] for b, l in enumerate(lens_t)]), dev, torch.int32).contiguous()
         x32 = GatherRowsFn.apply(dec.vocab_embedding.weight, tok, pos)
     else:
-        idx = torch.cat([torch.arange(b * T, b * T + l, dtype=torch.int32) for b, l in enumerate(lens_t)]).to(dev)
+        idx = ops.h2d(torch.cat([torch.arange(b * T, b * T + l, dtype=torch.int32) for b, l in enumerate(lens_t)]), dev)
         x32 = GatherRowsFn.apply(input_seqs.reshape(B * T, E).float(), idx, pos)
     cu_t, cu_s = EG.cu_from_lens(lens_t, dev), EG.cu_from_lens(lens_s, dev)
     memc = memc_shared if memc_shared is not None else (CastBf16Fn.apply(mem32) if bf else mem32)
