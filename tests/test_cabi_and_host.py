@@ -35,6 +35,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.AcaiDecLayer) == 8 * len(names)
     assert ctypes.sizeof(_lib.AcaiDecoder) == 20 * 4 + 8 * 23
     assert ctypes.sizeof(_lib.AcaiAdamWTensor) == 56 and ctypes.sizeof(_lib.AcaiAdamWGroup) == 32   # include/acai_omr_hip.h: AcaiAdamWTensor / AcaiAdamWGroup
+    assert ctypes.sizeof(_lib.AcaiCastEntry) == 48 and [f for f, _ in _lib.AcaiCastEntry._fields_] == ["src", "dst16", "dst16t", "dst32r", "rows", "cols", "tile0", "pad_"]
 
 
 def test_ops_refuse_cpu_tensors():
@@ -164,3 +165,14 @@ def test_grpo_host_helpers_reference_vectors():
     msk = torch.tensor([[F, F, T], [F, F, F]])
     lx, mx = g.expand_img_latent_for_rollout(lat, msk, 2)
     assert torch.equal(lx, torch.cat([lat[:1].repeat(2, 1, 1), lat[1:].repeat(2, 1, 1)])) and torch.equal(mx, torch.cat([msk[:1].repeat(2, 1), msk[1:].repeat(2, 1)]))
+
+
+def test_cu_seqlens_are_cached_per_lengths_and_uploads_pass_cpu_through():
+    """engine.cu_from_lens: int32 prefix sums, one tensor per (lengths, device) - a training loop asks for the same few every step - and
+    ops.h2d leaves a CPU destination alone (on a GPU it stages through pinned memory and copies without stalling the host)."""
+    from acai_omr_amd import engine, ops
+    a = engine.cu_from_lens([3, 5, 1], "cpu")
+    assert a.dtype == torch.int32 and a.tolist() == [0, 3, 8, 9]
+    assert engine.cu_from_lens((3, 5, 1), "cpu") is a and engine.cu_from_lens([3, 5, 2], "cpu") is not a
+    t = torch.arange(6, dtype=torch.int64)
+    assert ops.h2d(t, "cpu") is t and ops.h2d(t, "cpu", torch.int32).dtype == torch.int32
