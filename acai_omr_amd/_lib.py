@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("ACAI_OMR_LIB") or os.path.join(CSRC, "libacai_omr_hip.so")   # (override: A/B builds of the same sources, tools/ab_*.sh)
-SOURCES = ["gemm.hip", "elementwise.hip", "attn_varlen.hip", "attn_bwd.hip", "train.hip", "decode.hip", "resize.hip"]
+SOURCES = ["gemm.hip", "elementwise.hip", "attn_varlen.hip", "attn_fwd64.hip", "attn_fwd64w.hip", "attn_bwd.hip", "train.hip", "decode.hip", "resize.hip"]
 
 ACAI_F32, ACAI_BF16 = 0, 1
 GEMM_GELU, GEMM_ROUND_BF16 = 1, 2
@@ -81,6 +81,7 @@ _SIGNATURES = {
     "acai_mae_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "acai_ce_loss": (c_int, [c_void_p, c_int, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "acai_debug_stamps": (c_int, [c_void_p, c_int]),
+    "acai_debug_lds_dma_oob": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "acai_pe_interp_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "acai_pe_interp_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "acai_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
@@ -109,12 +110,14 @@ def build(force=False, verbose=False):
     source or a shared header is newer), compiled in parallel, then one link."""
     from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(CSRC), "..", "include", "acai_omr_hip.h")]
+    hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(os.path.dirname(CSRC), "..", "include", "acai_omr_hip.h")]
     hipcc = "hipcc" if subprocess.run(["which", "hipcc"], capture_output=True).returncode == 0 else "/opt/rocm/bin/hipcc"
     flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value"]
     # The attention kernels are bound by VALU issue, and the SLP vectoriser pairs their per-score multiplies into v_pk_mul_f32, which costs
     # more issue time than the two v_mul_f32 it replaces (PMC: +24 % VALU instructions without it, -9 % wave cycles).
-    per_file = {"attn_varlen.hip": ["-fno-slp-vectorize"], "attn_bwd.hip": ["-fno-slp-vectorize"]}
+    per_file = {"attn_varlen.hip": ["-fno-slp-vectorize"], "attn_fwd64.hip": ["-fno-slp-vectorize"],
+                # (one wave per SIMD: the score MFMAs must write VGPRs, the output accumulators are asm-owned AGPRs - see the file header)
+                "attn_fwd64w.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"], "attn_bwd.hip": ["-fno-slp-vectorize"]}
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
 

@@ -14,7 +14,7 @@
 // K=2 MFMA with A key (i&3)+8(i>>2)+4h).  bf16 -> v_mfma_f32_32x32x16_bf16, fp32 -> v_mfma_f32_32x32x2_f32.
 // Online softmax in fp32 with exp2 and a finite -1e30 floor; global loads of tile t+1 are issued before
 // the MFMAs of tile t (issue-early / write-late) into the other of two LDS stages: one barrier per tile.
-#include "common.h"
+#include "attn_args.h"
 
 #ifndef ACAI_ATTN_QK_FIRST
 #define ACAI_ATTN_QK_FIRST 0
@@ -33,18 +33,6 @@ namespace {
 
 constexpr int KT = 64;   // keys per tile
 constexpr int QB = 128;  // queries per workgroup
-
-struct AttnArgs {
-    const void *q, *k, *v;
-    void *out;
-    const int32_t *cu_q, *cu_k;
-    int ldq, ldk, ldv, ldo, H, dh, causal;
-    float scale_log2e;
-    uint32_t drop_thr, drop_seed;  // attention-probability dropout (nn.MultiheadAttention(dropout=p) in train mode): keep iff hash >= thr
-    float drop_scale;
-    float *lse;   // optional [H][total_q]: log2-domain log-sum-exp of the scaled scores (saved for the backward pass)
-    int total_q;
-};
 
 // NQ = 32-query blocks per wave (1 or 2).  NQ = 2: a wave owns 64 queries and every K / V^T fragment it reads from LDS feeds two MFMAs, one per
 // block; the tile loop's fixed costs (fragment reads, staging, waits, barrier, branches: ~150 of ~600 issue cycles per 2048 scores at d_h = 32)
@@ -561,6 +549,15 @@ int launch(const AttnArgs &a, int B, int max_q, bool pre, hipStream_t st) {
             static const int nq_env = getenv("ACAI_ATTN_NQ") ? atoi(getenv("ACAI_ATTN_NQ")) : 2;
             // (d_h = 64 keeps one block: two need 256 registers + 55 spilt even with the zero reference, and measured 5 % slower - 0.97 against 0.92 ms)
             bool two = false;
+            if constexpr (DHP == 64) {
+                // d_h = 64 exactly, no causal mask: the software-pipelined kernel of attn_fwd64.hip (ACAI_ATTN64=0: this file's kernel, A/B aid)
+                static const int f64_env = getenv("ACAI_ATTN64") ? atoi(getenv("ACAI_ATTN64")) : 1;
+                if (f64_env && a.dh == 64 && !a.causal) {
+                    const int rc = acai_attn_fwd64_launch(a, B, max_q, st);
+                    ACAI_LAUNCH_CHECK("acai_attn_varlen_fwd");
+                    return rc;
+                }
+            }
             if constexpr (DHP == 32) {
                 two = nq_env == 2 && max_q >= 512;
                 if (two) hipLaunchKernelGGL((attn_fwd_kernel<T, DHP, true, false, true, 2>), dim3(cdiv(max_q, 2 * QB), a.H, B), dim3(256), 0, st, a);

@@ -281,3 +281,28 @@ extern "C" int acai_graph_destroy(void *graph_exec) {
     if (e != hipSuccess) return acai_set_err((int)e, "hipGraphExecDestroy: %s", hipGetErrorString(e));
     return 0;
 }
+
+
+// ---- hardware-assumption probe: out-of-range lanes of a buffer LDS-DMA (see include/acai_omr_hip.h) -------------------------------------------
+namespace {
+__global__ __launch_bounds__(64) void lds_dma_oob_probe_kernel(const uint32_t *src, int valid_bytes, uint32_t *out) {
+    __shared__ __attribute__((aligned(16))) uint32_t img[64 * 4];
+    for (int i = threadIdx.x; i < 256; i += 64) img[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(src), 0, valid_bytes, 0x00020000);
+    const uint32_t voff = threadIdx.x * 16;
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    const uint32_t dst = (uint32_t)(uintptr_t)(lds_ptr)img;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_waitcnt vmcnt(0)" ::"s"(dst), "v"(voff), "s"(rs) : "memory", "m0");
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += 64) out[i] = img[i];
+}
+}  // namespace
+
+extern "C" int acai_debug_lds_dma_oob(const void *src, int valid_bytes, void *out, void *stream) {
+    ACAI_CHECK_ARG(src && out && valid_bytes >= 0 && valid_bytes <= 1024, "acai_debug_lds_dma_oob: bad arguments");
+    hipLaunchKernelGGL(lds_dma_oob_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t *>(src), valid_bytes,
+                       reinterpret_cast<uint32_t *>(out));
+    ACAI_LAUNCH_CHECK("acai_debug_lds_dma_oob");
+    return 0;
+}

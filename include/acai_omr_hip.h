@@ -111,6 +111,12 @@ int acai_pe_interp_bwd(const float *dout, int Hout, int Wout, int E, float *dtab
 /* Diagnostic aid (tools/stamp_decode.py): s_memrealtime stamps of the decode GEMV kernel's stages, buf[launch][1024][8] uint64. */
 int acai_debug_stamps(void *buf, int cap_launches);
 
+/* Hardware-assumption probe (tests/test_gpu_kernels.py::test_lds_dma_out_of_range_lanes_write_zeros): one wave issues the weight-gradient
+ * GEMMs' `buffer_load_dwordx4 ... offen lds` (gemm_tn_glds / gemm_tn_pp kernels, ragged last token tile) over a 1 KiB LDS image preset to
+ * 0xFFFFFFFF with a resource of `valid_bytes` bytes at `src`; out[256] receives the image.  The kernels rely on lanes past num_records
+ * writing ZEROS (observed on gfx950 / ROCm 7.2, not documented): a ROCm change shows up as a red test instead of wrong gradients. */
+int acai_debug_lds_dma_oob(const void *src, int valid_bytes, void *out, void *stream);
+
 /* autocast's fp32 -> bf16 input cast (round to nearest even) for an activation that feeds a bf16 GEMM. */
 int acai_cast_f32_bf16(const float *x, void *y, int64_t n, void *stream);
 

@@ -215,6 +215,86 @@ def test_attn_varlen_two_block_forward_zero_reference_restart(dev, shift):
     assert float(lse.abs().min()) > 100.0        # the scores really are that far from zero
 
 
+@pytest.mark.parametrize("H,lens_q,lens_k", [
+    (2, [513, 640, 1], None),                 # ragged ends, a one-row sequence, a fifth 128-query block holding one row
+    (3, [513, 130], [4096 + 17, 64]),         # the teacher-forced cross attention's shape; exactly one full tile
+    (1, [40, 129, 192], [40, 65, 191]),       # one ragged tile; two tiles with one key in the second; three tiles
+    (2, [300], [128]),                        # two full tiles: prologue + one steady tile + drain, nothing masked
+    (1, [256], [1]),                          # a single key
+])
+def test_attn_fwd64_pipelined(dev, H, lens_q, lens_k):
+    """attn_fwd64.hip (bf16, d_h = 64, q prescaled, no mask): the software-pipelined forward against the fp64 softmax, every tile-count class
+    of its prologue / steady / masked / drain structure, with the log-sum-exp it hands to the backward pass."""
+    from acai_omr_amd import engine, ops
+    dh, bf = 64, torch.bfloat16
+    lens_k = lens_k or lens_q
+    E = H * dh
+    g = torch.Generator().manual_seed(H + sum(lens_q) + sum(lens_k))
+    q = rb(torch.randn(sum(lens_q), E, generator=g) * 2.0 * ops.QSCALE(dh))
+    k, v = rb(torch.randn(sum(lens_k), E, generator=g)), rb(torch.randn(sum(lens_k), E, generator=g))
+    cu_q, cu_k = engine.cu_from_lens(lens_q, dev), engine.cu_from_lens(lens_k, dev)
+    lse = torch.full((H * sum(lens_q),), float("nan"), device=dev)
+    out = ops.attn_varlen(q.to(dev).to(bf), k.to(dev).to(bf), v.to(dev).to(bf), cu_q, cu_k, H, dh, max(lens_q), lse=lse, q_prescaled=True)
+    q_ref = q.double() / ops.QSCALE(dh)
+    ref = ref_attn(q_ref, k, v, lens_q, lens_k, H, dh, False)
+    assert (out.cpu().double() - ref).abs().max() < 1.2e-2 * max(1.0, float(ref.abs().max()))
+    # lse[h][q] = log2 sum_k 2^(q' . k)
+    oq = ok = 0
+    lse = lse.cpu().double().view(H, -1)
+    for lq, lk in zip(lens_q, lens_k):
+        for h in range(H):
+            sl = slice(h * dh, (h + 1) * dh)
+            s = q[oq:oq + lq, sl].double() @ k[ok:ok + lk, sl].double().T
+            want = torch.logsumexp(s * math.log(2.0), -1) / math.log(2.0)
+            assert (lse[h, oq:oq + lq] - want).abs().max() < 2e-2
+        oq += lq
+        ok += lk
+
+
+@pytest.mark.parametrize("shift", [-4.0, 4.0])
+@pytest.mark.parametrize("lens", [[600, 520], [513, 70]])
+def test_attn_fwd64_zero_reference_restart(dev, shift, lens):
+    """attn_fwd64.hip takes probabilities as 2^score against a ZERO reference.  Rows whose scores all sit ~180 below (above) zero in the log2
+    domain underflow (overflow) every probability: the row sum leaves (2^-100, 2^100), the workgroup takes the exact row maxima in a pre-pass
+    and runs the same loop again with the scores starting at -m.  One sequence of the batch restarts, the other (ordinary scores) does not."""
+    from acai_omr_amd import engine, ops
+    H, dh, bf = 2, 64, torch.bfloat16
+    E = H * dh
+    g = torch.Generator().manual_seed(29)
+    q = torch.randn(sum(lens), E, generator=g) * 0.1 + 4.0
+    k = torch.randn(sum(lens), E, generator=g) * 0.05 + shift
+    v = torch.randn(sum(lens), E, generator=g)
+    q[lens[0]:] = torch.randn(lens[1], E, generator=g)          # second sequence: ordinary scores
+    k[lens[0]:] = torch.randn(lens[1], E, generator=g)
+    k[lens[0] + 5] *= 30.0                                      # ... except for one key that overflows some rows and underflows none
+    q, k, v = (t.to(bf).float() for t in (q, k, v))
+    qd = (q * ops.QSCALE(dh)).to(bf)
+    cu = engine.cu_from_lens(lens, dev)
+    lse = torch.empty(H * sum(lens), device=dev)
+    out = ops.attn_varlen(qd.to(dev), k.to(dev).to(bf), v.to(dev).to(bf), cu, cu, H, dh, max(lens), lse=lse, q_prescaled=True)
+    ref = ref_attn(qd.double() / ops.QSCALE(dh), k, v, lens, lens, H, dh, False)
+    assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(lse).all())
+    assert (out.cpu().double() - ref).abs().max() < 1.2e-2 * max(1.0, float(ref.abs().max()))
+    assert float(lse.view(H, -1)[:, :lens[0]].abs().min()) > 100.0        # the first sequence's scores really are that far from zero
+
+
+@pytest.mark.parametrize("valid", [0, 8, 40 * 16, 40 * 16 + 8, 63 * 16 + 12, 1024])
+def test_lds_dma_out_of_range_lanes_write_zeros(dev, valid):
+    """The weight-gradient GEMMs fetch a ragged last token tile with `buffer_load_dwordx4 ... offen lds` through a resource whose num_records
+    ends at the last token that exists, and rely on the lanes beyond it writing ZEROS into LDS (so that no second, register-staged launch is
+    needed for the 16-token remainder of the 16 x 513 decoder stream).  That is observed gfx950 / ROCm 7.2 behaviour (per dword, only the
+    VGPR offset is range-checked), not a documented guarantee - this test pins it."""
+    from acai_omr_amd import _lib
+    src = (torch.arange(256, dtype=torch.int32) + 0x1000).to(dev)
+    out = torch.full((256,), -2, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().acai_debug_lds_dma_oob(src.data_ptr(), valid, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "acai_debug_lds_dma_oob")
+    torch.cuda.synchronize()
+    want = torch.arange(256, dtype=torch.int32) + 0x1000
+    want[(valid + 3) // 4:] = 0      # every dword that does not lie wholly inside the resource reads as zero - never stale LDS bytes (0xFFFFFFFF)
+    want[valid // 4:(valid + 3) // 4] = 0
+    assert torch.equal(out.cpu(), want), (valid, out.cpu()[max(0, valid // 4 - 4):valid // 4 + 8])
+
+
 def test_patchify_and_gather(dev):
     from acai_omr_amd import ops
     from oracle import vitomr_oracle as O
