@@ -124,11 +124,20 @@ def build(force=False, verbose=False):
     def stale(out, deps):
         return force or not os.path.exists(out) or any(os.path.getmtime(out) < os.path.getmtime(d) for d in deps)
 
-    jobs = []
+    # Sources whose correctness rests on something the compiler does not model (asm loads it cannot see, a counted LDS wait): their generated
+    # assembly is checked on every rebuild and a hit FAILS the build (acai_omr_amd/_asmcheck.py; ADVICE r3: the check used to be a manual tool).
+    asm_checks = {"gemm.hip": "check_untracked_loads", "attn_fwd64w.hip": "check_fwd64w_barrier"}
+    jobs, to_check = [], []
     for src in srcs:
-        obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        if stale(obj, [src] + hdrs):
-            jobs.append([hipcc] + flags + per_file.get(os.path.basename(src), []) + ["-c", src, "-o", obj])
+        base = os.path.basename(src)
+        obj = os.path.join(objdir, base + ".o")
+        asm = os.path.join(objdir, base + ".s")
+        rebuilt = stale(obj, [src] + hdrs)
+        if rebuilt:
+            jobs.append([hipcc] + flags + per_file.get(base, []) + ["-c", src, "-o", obj])
+        if base in asm_checks and (rebuilt or stale(asm, [src] + hdrs)):
+            jobs.append([hipcc] + flags + per_file.get(base, []) + ["--cuda-device-only", "-S", src, "-o", asm])
+            to_check.append((base, asm))
     if verbose:
         for j in jobs:
             print(" ".join(j))
@@ -137,6 +146,14 @@ def build(force=False, verbose=False):
             for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
                 if r.returncode != 0:
                     raise RuntimeError(f"hipcc failed: {' '.join(r.args)}\n{r.stdout}\n{r.stderr}")
+    from . import _asmcheck
+    for base, asm in to_check:
+        problems, n = getattr(_asmcheck, asm_checks[base])(open(asm).read())
+        if verbose:
+            print(f"asm check {base}: {n} sites, {len(problems)} problems")
+        if problems:
+            os.remove(asm)   # (so that the next build checks again instead of trusting a stale pass)
+            raise RuntimeError(f"generated code of {base} violates an assumption the kernel relies on:\n" + "\n".join(problems))
     objs = [os.path.join(objdir, os.path.basename(src) + ".o") for src in srcs]
     if jobs or stale(LIB_PATH, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs

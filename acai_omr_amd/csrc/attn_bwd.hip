@@ -935,21 +935,19 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, bool pre, hipStrea
     if (pre && !fast) return acai_set_err(-1, "acai_attn_varlen_bwd: q_prescaled needs 16-byte aligned operands and d_h %% %d == 0", EPC);
     auto launch_pair = [&](auto drop, auto fst, auto pr) {
         constexpr bool D = decltype(drop)::value, F = decltype(fst)::value, P = decltype(pr)::value;
-        static bool attr = false;  // one flag per instantiation
-        if (!attr) {
+        static bool attr[ACAI_MAX_DEV] = {};  // one latch per instantiation and device
+        if (acai_first_on_device(attr)) {
             hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_kernel<T, DHP, F, D, P>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_kernel<T, DHP, F, D, P>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            attr = true;
         }
         dim3 gq(cdiv(max_q, OB), a.H, B), gk(cdiv(max_k, OB), a.H, B);
         if constexpr (sizeof(T) == 2 && DHP == 32 && F && !D && P) {
             // the training steps' form on long sequences: two lane-owned blocks per wave (ACAI_ATTN_NQ=1: the one-block kernels, A/B aid)
             static const int nq_env = getenv("ACAI_ATTN_NQ") ? atoi(getenv("ACAI_ATTN_NQ")) : 2;
-            static bool attr2 = false;
-            if (!attr2) {
+            static bool attr2[ACAI_MAX_DEV] = {};
+            if (acai_first_on_device(attr2)) {
                 hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
                 hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                attr2 = true;
             }
             if (nq_env == 2 && !a.causal && max_q >= 512 && max_k >= 512) {
                 hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(cdiv(max_q, 2 * OB), a.H, B), dim3(256), lds_dq, st, a);

@@ -158,4 +158,14 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// Once-per-DEVICE latch for hipFuncSetAttribute and the like (function attributes are per device; a per-process `static bool` skipped the
+// call for every device after the first when one process drives several GPUs).  Usage: static bool seen[ACAI_MAX_DEV]; if (acai_first_on_device(seen)) ...
+constexpr int ACAI_MAX_DEV = 64;
+static inline bool acai_first_on_device(bool (&seen)[ACAI_MAX_DEV]) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= ACAI_MAX_DEV) return true;   // unknown device: just do the (idempotent) call
+    if (seen[d]) return false;
+    seen[d] = true;
+    return true;
+}
 static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }

@@ -17,6 +17,9 @@
 
 #include "common.h"
 
+#include <mutex>
+#include <unordered_map>
+
 namespace {
 
 constexpr int SK_KC = 1024;  // k elements of x staged in LDS per pass
@@ -646,13 +649,12 @@ int launch_skinny(const SkinnyArgs &a, hipStream_t st) {
             const int rows = a.B < 16 ? ((a.B + 3) & ~3) : 16;
             const bool wide = a.x_bf16 && a.K == 4096;  // 16 K-slices: every weight fragment of the workgroup in flight at once
             const size_t lds = (wide ? 16 : 4) * 1024 + (size_t)rows * (a.K * 2 + 16);
-            static bool attr_done = false;
-            if (!attr_done) {  // opt in to > 64 KB of dynamic LDS (K = 4096 activation image)
+            static bool attr_done[ACAI_MAX_DEV] = {};
+            if (acai_first_on_device(attr_done)) {  // opt in to > 64 KB of dynamic LDS (K = 4096 activation image); per device
                 hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_mfma_kernel<false, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
                 hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_mfma_kernel<false, 16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
                 hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_mfma_kernel<true, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
                 hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_mfma_kernel<true, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-                attr_done = true;
             }
             // one CU ingests only ~25 GB/s from HBM: spread a small weight matrix over >= ~200 workgroups by giving each
             // fewer than 16 rows (the unused MFMA rows load nothing)
@@ -671,11 +673,10 @@ int launch_skinny(const SkinnyArgs &a, hipStream_t st) {
             const bool chain_ok = !no_chain && (size_t)a.N * a.ldw * 2 < 0xFFF00000u && (a.ldx % 8 == 0);   // (row statistics are only published with a LayerNorm on load, as in skinny_mfma_kernel)
             if (a.ln2_w && !(chain_ok && a.K == 1024 && !a.x_bf16 && a.ln_w)) return acai_set_err(-1, "skinny_gemm: the double LayerNorm needs the chain kernel (K = 1024, fp32 activations)");
             if (chain_ok && ((a.K == 1024 && !a.x_bf16) || (a.K == 4096 && a.x_bf16 && !a.ln_w))) {
-                static bool attr2 = false;
-                if (!attr2) {
+                static bool attr2[ACAI_MAX_DEV] = {};
+                if (acai_first_on_device(attr2)) {
                     hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_chain_kernel<true, 0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
                     hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_chain_kernel<true, 0, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-                    attr2 = true;
                 }
                 const dim3 cgrid(cdiv(a.N, b.rows_per_block), cdiv(a.B, 16));
                 const int nw = a.x_bf16 ? 16 : 4;
@@ -1379,6 +1380,49 @@ int launch_dattn(const DAttnArgs &a, int B, hipStream_t st) {
     return 0;
 }
 
+// The in-launch merge of the split partials (decode_attn_kernel: write-through stores, one agent-scope ticket per (sequence, head), the last
+// arriver loads every partial) is a hand-off MEASURED on gfx950 / ROCm 7.2 with this kernel at TWO resident workgroups per CU - not an
+// architectural guarantee (MI355X_MICROARCH.md, "Valid forms").  If a toolchain change moves the kernel's register count so that the residency
+// is no longer the one it was validated at, the step falls back to the separate combine launch by itself (tickets ignored) instead of running
+// the hand-off in a regime nobody tested.  ACAI_DATTN_MERGE=1 / 0 forces either path (A/B aid).
+template <typename TC>
+bool dattn_merge_validated(int dhp) {
+    static int cached[5] = {-1, -1, -1, -1, -1};   // per lanes-per-key variant: 1, 2, 4, 8, 16
+    static const int force = getenv("ACAI_DATTN_MERGE") ? atoi(getenv("ACAI_DATTN_MERGE")) : -1;
+    if (force >= 0) return force != 0;
+    const int lpk = dhp * (int)sizeof(TC) / 16;
+    int idx = lpk == 1 ? 0 : lpk == 2 ? 1 : lpk == 4 ? 2 : lpk == 8 ? 3 : lpk == 16 ? 4 : -1;
+    if (idx < 0) return false;
+    if (cached[idx] < 0) {
+        int n = 0;
+        hipError_t e = hipErrorUnknown;
+        switch (lpk) {
+#define ACAI_OCC(L) case L: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(&decode_attn_kernel<TC, L, true>), 256, 0); break;
+            ACAI_OCC(1) ACAI_OCC(2) ACAI_OCC(4) ACAI_OCC(8) ACAI_OCC(16)
+#undef ACAI_OCC
+        }
+        cached[idx] = (e == hipSuccess && n == 2) ? 1 : 0;
+    }
+    return cached[idx] == 1;
+}
+
+// Host-side record of "d->x holds the chained step's input embedding" per decoder state (keyed by the x buffer): acai_decode_embed sets it,
+// acai_decode_step / acai_decode_sample_step require it (they no longer embed by themselves: their input is what the previous step's argmax
+// kernel wrote) and keep it, acai_decode_logits / acai_decode_hidden clear it (they overwrite x).  A C-ABI caller that mixes the stepwise and
+// the chained entry points without re-embedding gets an argument error instead of a step on stale input.  (Replays of a captured graph do
+// not pass through here: the capture-time call is what is checked - INTEGRATION.md.)
+static std::mutex g_xv_mu;
+static std::unordered_map<const void *, bool> g_x_valid;
+static void x_valid_set(const AcaiDecoder *d, bool v) {
+    std::lock_guard<std::mutex> lk(g_xv_mu);
+    g_x_valid[d->x] = v;
+}
+static bool x_valid_get(const AcaiDecoder *d) {
+    std::lock_guard<std::mutex> lk(g_xv_mu);
+    auto it = g_x_valid.find(d->x);
+    return it != g_x_valid.end() && it->second;
+}
+
 int check_decoder(const AcaiDecoder *d) {
     ACAI_CHECK_ARG(d && d->layers, "decoder: null descriptor");
     ACAI_CHECK_ARG(d->B > 0 && d->L > 0 && d->E == d->H * d->dh && d->dhp >= d->dh && d->dhp <= 64 && (d->dhp & (d->dhp - 1)) == 0 &&
@@ -1432,7 +1476,7 @@ int decode_core(const AcaiDecoder *d, const int64_t *tokens, hipStream_t st, boo
             a.out = d->attn; a.ldo = E; a.round_out = rnd ? 1 : 0;
             return group > 1 ? launch_dattn_group(a, B, group, st) : launch_dattn<TW>(a, B, st);
         }
-        if (d->tickets) {
+        if (d->tickets && (group > 1 || dattn_merge_validated<TW>(d->dhp))) {
             a.out = d->attn; a.ldo = E; a.round_out = rnd ? 1 : 0; a.tickets = d->tickets;
             return group > 1 ? launch_dattn_group(a, B, group, st) : launch_dattn<TW>(a, B, st);
         }
@@ -1619,6 +1663,7 @@ extern "C" int acai_decode_hidden(const AcaiDecoder *d, const float *x_in, void 
     if (rc) return rc;
     hipLaunchKernelGGL(advance_cache_kernel, dim3(1), dim3(1), 0, st, d->step);
     ACAI_LAUNCH_CHECK("advance_cache");
+    x_valid_set(d, false);
     return 0;
 }
 
@@ -1631,6 +1676,7 @@ extern "C" int acai_decode_embed(const AcaiDecoder *d, void *stream) {
     hipLaunchKernelGGL(embed_kernel, dim3(d->B), dim3(256), 0, (hipStream_t)stream, (const float *)d->emb, (const float *)d->pos, (const int64_t *)nullptr,
                        (const int64_t *)d->seqs, (const int32_t *)d->step, d->max_len, d->x, d->E);
     ACAI_LAUNCH_CHECK("embed");
+    x_valid_set(d, true);
     return 0;
 }
 
@@ -1642,6 +1688,8 @@ extern "C" int acai_decode_step(const AcaiDecoder *d, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     // the step's input x was written by the previous step's argmax (or by acai_decode_embed after arming) when E allows 16-byte rows
     const bool chained = (d->E % 4 == 0);
+    ACAI_CHECK_ARG(!chained || x_valid_get(d), "acai_decode_step: x does not hold this step's input embedding - call acai_decode_embed after arming the "
+                                               "sequence state and after every acai_decode_logits / acai_decode_hidden");
     rc = d->dtype == ACAI_BF16 ? decode_core<bf16_t>(d, nullptr, st, !chained) : decode_core<float>(d, nullptr, st, !chained);
     if (rc) return rc;
     hipLaunchKernelGGL(argmax_logprob_kernel, dim3(1), dim3(d->B > 8 ? 1024 : (d->B > 4 ? 512 : 256)), 0, st, d->logits, d->V, d->B, d->seqs, d->logprobs, d->max_len, d->step,
@@ -1659,6 +1707,8 @@ extern "C" int acai_decode_sample_step(const AcaiDecoder *d, const float *unifor
                    "acai_decode_sample_step: needs uniforms, 1 <= top_k <= 64, temperature > 0, vocabulary <= 512 (top_k=%d V=%d)", top_k, d->V);
     hipStream_t st = (hipStream_t)stream;
     const bool chained = (d->E % 4 == 0);
+    ACAI_CHECK_ARG(!chained || x_valid_get(d), "acai_decode_sample_step: x does not hold this step's input embedding - call acai_decode_embed after arming "
+                                               "the sequence state and after every acai_decode_logits / acai_decode_hidden");
     rc = d->dtype == ACAI_BF16 ? decode_core<bf16_t>(d, nullptr, st, !chained) : decode_core<float>(d, nullptr, st, !chained);
     if (rc) return rc;
     hipLaunchKernelGGL(sample_logprob_kernel, dim3(cdiv(d->B, 4)), dim3(256), 0, st, d->logits, d->V, d->B, d->seqs, d->logprobs, d->max_len, d->step,
@@ -1680,5 +1730,6 @@ extern "C" int acai_decode_logits(const AcaiDecoder *d, const int64_t *tokens, i
     if (rc) return rc;
     hipLaunchKernelGGL(advance_cache_kernel, dim3(1), dim3(1), 0, st, d->step);
     ACAI_LAUNCH_CHECK("advance_cache");
+    x_valid_set(d, false);
     return 0;
 }

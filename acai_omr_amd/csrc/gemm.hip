@@ -35,6 +35,7 @@ struct GemmArgs {
     float col_scale;
     // dW form (TA && TB): also accumulate the column sums of the token-major A operand (= the bias gradient next to dW = dY^T X) into colsum[M]
     float *colsum;
+    int *colsum_done;   // host-side out flag of the dW dispatch: the launched kernel formed `colsum` itself (acai_gemm_dw runs a separate pass otherwise)
     // EPI == 1 (cross K/V prefill scatter)
     const int32_t *row_seq, *row_pos, *seq_len;
     const int64_t *seq_off;
@@ -1439,7 +1440,11 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
                 uint32_t x0 = pack_bf16(v[0][0], v[0][1]), x1 = pack_bf16(v[0][2], v[0][3]), y0 = pack_bf16(v[1][0], v[1][1]), y1 = pack_bf16(v[1][2], v[1][3]);
                 pp_swap2(x0, y0);
                 pp_swap2(x1, y1);
+#ifdef ACAI_GEMM_ABLATE
                 const int dbg = g.flags >> 8;
+#else
+                constexpr int dbg = 0;
+#endif
                 if (dbg & 128) asm volatile("" ::"v"(x0), "v"(x1), "v"(y0), "v"(y1));
                 else __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{x0, x1, y0, y1}, rc, (dbg & 64) ? (off_sw_c & 0xFFFF0u) : off_sw_c, 0, 0);
             }
@@ -1491,9 +1496,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     typedef __attribute__((address_space(3))) void *lds_ptr;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr)lds;
 
-    // timing ablations (ACAI_GEMM_DEBUG, results are wrong): 1 no counted waits, 2 no LDS-DMA, 4 no epilogue, 8 no MFMAs, 16 no fragment reads,
-    // 32 start-up skew of the workgroups
+    // timing ablations (-DACAI_GEMM_ABLATE builds only - tools/ablate_pp.py, tools/build_variant.sh; ACAI_GEMM_DEBUG bits, results are wrong):
+    // 1 no counted waits, 2 no LDS-DMA, 4 no epilogue, 8 no MFMAs, 16 no fragment reads, 32 start-up skew of the workgroups.  The production
+    // build compiles them out (a stray high flag bit or a leftover environment variable silently dropped stores).
+#ifdef ACAI_GEMM_ABLATE
     const int dbg = g.flags >> 8;
+#else
+    constexpr int dbg = 0;
+#endif
     // ---- producer (as pers256): one cursor per operand, A runs one K-step ahead of W ----
     // Sources as a uniform base (SGPR pair: the tile's first row, advanced per K-step) + a 32-bit byte offset per lane: (row within the tile,
     // clamped to the operand's last row) x pitch + the swizzled 16-byte slot.  24-bit multiplies (the host checks pitch < 2^24 bytes).
@@ -2146,7 +2156,6 @@ static inline bool pp_mode_ok(int m) {
 }
 
 int g_gemm_variant = getenv("ACAI_GEMM_VARIANT") ? atoi(getenv("ACAI_GEMM_VARIANT")) : 0;
-int g_tn_colsum_done = 0;   // set by the dW dispatch when the launched kernel also formed the column sums (acai_gemm_dw: else a separate pass)
 
 template <typename T, int EPI, bool TA = false, bool TB = false>
 int launch(const GemmArgs &g, hipStream_t st) {
@@ -2201,7 +2210,7 @@ int launch(const GemmArgs &g, hipStream_t st) {
                 m.ksplit = ks_p;
                 m.K = g.K;
                 m.colsum = want_cs;
-                g_tn_colsum_done = want_cs != nullptr;
+                if (g.colsum_done) *g.colsum_done = want_cs != nullptr;   // (a per-call out flag: a process global raced between devices' backward threads)
                 whole = true;
                 hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3(tiles_p * ks_p), dim3(512), 0, st, m);
             } else if (!no_ring && ks_r >= 1 && nkt_r >= 16 && pp_fits) {
@@ -2289,7 +2298,9 @@ int launch(const GemmArgs &g, hipStream_t st) {
         switch (v) {
             case 7:
                 if constexpr (sizeof(T) == 2 && EPI == 0) {
+#ifdef ACAI_GEMM_ABLATE
                     if (const char *d = getenv("ACAI_GEMM_DEBUG")) h.flags |= atoi(d) << 8;
+#endif
                     const dim3 grid(nwg256 < n_cu ? nwg256 : n_cu), block(512);
                     int mode = pp_mode(h);
                     // the GELU forms can defer their GELU step into the next tile's R segments (see PP_DEFER) when a tile has enough of them;
@@ -2350,6 +2361,7 @@ extern "C" int acai_gemm_nt_ex(const void *A, int lda, const void *W, int ldw, c
     ACAI_CHECK_ARG(aux_mode >= 0 && aux_mode <= 2 && (aux_mode == 0 || (aux && ldaux >= N)), "acai_gemm_nt_ex: bad aux operand (mode %d)", aux_mode);
     ACAI_CHECK_ARG(aux_mode != 1 || (flags & ACAI_GEMM_GELU), "acai_gemm_nt_ex: aux_mode 1 keeps the pre-activation of a GELU epilogue");
     ACAI_CHECK_ARG(aux_mode != 2 || !(flags & ACAI_GEMM_GELU), "acai_gemm_nt_ex: aux_mode 2 (GELU derivative) excludes the GELU flag");
+    ACAI_CHECK_ARG((flags & ~(ACAI_GEMM_GELU | ACAI_GEMM_ROUND_BF16)) == 0, "acai_gemm_nt: unknown flag bits 0x%x", flags);
     if (M == 0) return 0;
     GemmArgs g{};
     g.A = A; g.W = W; g.bias = bias; g.residual = residual; g.C = C;
@@ -2373,6 +2385,7 @@ extern "C" int acai_gemm_nt(const void *A, int lda, const void *W, int ldw, cons
 extern "C" int acai_gemm(const void *A, int lda, int trans_a, const void *W, int ldw, int trans_w, const float *bias, const float *residual,
                          int ldr, void *C, int ldc, int M, int N, int K, int in_dtype, int out_dtype, int flags, void *stream) {
     ACAI_CHECK_ARG(A && W && C, "acai_gemm: null operand");
+    ACAI_CHECK_ARG((flags & ~(ACAI_GEMM_GELU | ACAI_GEMM_ROUND_BF16)) == 0, "acai_gemm: unknown flag bits 0x%x", flags);
     ACAI_CHECK_ARG(M >= 0 && N > 0 && K > 0, "acai_gemm: bad shape M=%d N=%d K=%d", M, N, K);
     ACAI_CHECK_ARG(lda >= (trans_a ? M : K) && ldw >= (trans_w ? N : K) && ldc >= N && (!residual || ldr >= N), "acai_gemm: leading dimension smaller than row");
     ACAI_CHECK_ARG((in_dtype == ACAI_F32 || in_dtype == ACAI_BF16) && (out_dtype == ACAI_F32 || out_dtype == ACAI_BF16), "acai_gemm: bad dtype");
@@ -2412,11 +2425,12 @@ extern "C" int acai_gemm_dw(const void *dY, int ldy, const void *X, int ldx, flo
     g.A = dY; g.W = X; g.C = dW; g.lda = ldy; g.ldw = ldx; g.ldc = lddw; g.M = M; g.N = N; g.K = K;
     g.out_dtype = ACAI_F32;
     g.colsum = dtype == ACAI_BF16 ? db : nullptr;
-    g_tn_colsum_done = 0;
+    int colsum_done = 0;   // set by the dispatch when the launched kernel also formed the column sums (else: a separate pass below)
+    g.colsum_done = &colsum_done;
     hipStream_t st = (hipStream_t)stream;
     const int rc = dtype == ACAI_BF16 ? launch<bf16_t, 0, true, true>(g, st) : launch<float, 0, true, true>(g, st);
     if (rc) return rc;
-    if (db && !g_tn_colsum_done) return acai_colsum(dY, ldy, db, K, M, dtype, stream);
+    if (db && !colsum_done) return acai_colsum(dY, ldy, db, K, M, dtype, stream);
     return 0;
 }
 

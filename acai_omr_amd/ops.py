@@ -134,6 +134,7 @@ class _ZeroArena:
     fills, the teacher-forced step ~700).  A slice becomes `param.grad` (autograd keeps the tensor it is handed), so a chunk lives exactly as
     long as the gradients cut from it; a fresh chunk is taken from torch's caching allocator when the current one is used up."""
     CHUNK = 64 << 20   # elements (256 MB)
+    SMALL_CHUNK, SMALL_MAX = 1 << 20, 1 << 16   # 4 MB chunks for slices of up to 256 KB: bias / LayerNorm / column-sum accumulators
 
     def __init__(self):
         self._buf, self._off = {}, {}
@@ -143,11 +144,14 @@ class _ZeroArena:
         if n >= self.CHUNK // 4:
             return torch.zeros(rows, cols, dtype=torch.float32, device=device)
         # one arena per (device, stream): a chunk is zero-filled on the stream that is current when it is created, and every slice of it is
-        # consumed by a GEMM launched on that same stream (ops launch on torch's current stream), so fill and use are ordered
-        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+        # consumed by a GEMM launched on that same stream (ops launch on torch's current stream), so fill and use are ordered.
+        # Small slices (the 1-D accumulators that become bias / LayerNorm gradients) come from their own 4 MB chunks: a caller that keeps one
+        # such gradient after training must not pin a 256 MB weight-gradient chunk with it.
+        small = n <= self.SMALL_MAX
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, small)
         buf, off = self._buf.get(key), self._off.get(key, 0)
         if buf is None or off + n > buf.numel():
-            buf, off = torch.zeros(self.CHUNK, dtype=torch.float32, device=device), 0
+            buf, off = torch.zeros(self.SMALL_CHUNK if small else self.CHUNK, dtype=torch.float32, device=device), 0
             self._buf[key] = buf
         self._off[key] = off + ((n + 63) & ~63)   # 256-byte aligned slices
         return buf[off:off + n].view(rows, cols)

@@ -174,6 +174,25 @@ def cpu_baseline_mae(height, width):
                 sample=f"1 image {height}x{width}: forward + MAELoss + backward through the CPU oracle (autocast(bf16) restatement, torch autograd), no optimizer step")
 
 
+def dist_info(dist, dev, backend):
+    """What the line was measured on: the process-group backend as torch reports it ("nccl" = RCCL over xGMI on ROCm, "gloo" = a rehearsal
+    without collectives on the GPUs), the world size it saw and every rank's device name - so that a scaling record cannot be mistaken for
+    something it is not."""
+    name = torch.cuda.get_device_name(dev) if dev.type == "cuda" else "cpu"
+    if dist is None:
+        return dict(backend=None, world_size=1, devices=[f"rank 0: {name} ({dev})"])
+    names = [None] * dist.get_world_size()
+    dist.all_gather_object(names, f"rank {dist.get_rank()}: {name} ({dev})")
+    return dict(backend=dist.get_backend(), world_size=dist.get_world_size(), devices=names,
+                transport="RCCL over xGMI" if dist.get_backend() == "nccl" else f"{dist.get_backend()} (host memory: a rehearsal, not a scaling measurement)")
+
+
+def _allreduce_label(dist):
+    if dist is None:
+        return ""
+    return " + RCCL gradient all-reduce" if dist.get_backend() == "nccl" else f" + {dist.get_backend()} gradient all-reduce (rehearsal backend, not RCCL)"
+
+
 def _barrier_sync(dist):
     torch.cuda.synchronize()
     if dist is not None:
@@ -202,7 +221,7 @@ def _timed_steps(step, steps, dist, dev, warm=2):   # (two: the second step is t
 
 
 # ---- config 2: MAE --------------------------------------------------------------------------------------------------------------------------
-def bench_mae(dev, rank, world, dist, batch, height, width, steps, dtype, want_cpu):
+def bench_mae(dev, rank, world, dist, batch, height, width, steps, dtype, want_cpu, comm_dtype="fp32"):
     """Second half of the BASELINE.json metric: MAE images/sec = images / (forward + MAELoss + backward [+ DP gradient all-reduce] + AdamW
     (pre_train.py:54-62: lr 1.5e-4, betas (0.9, 0.95), weight decay 0.05, here the fused multi-tensor kernel)) on `batch` synthetic HxW
     images per GPU, full-size MAE(0.75, 16, 60, 200) (pre_train.py:156-159)."""
@@ -216,7 +235,7 @@ def bench_mae(dev, rank, world, dist, batch, height, width, steps, dtype, want_c
     from acai_omr_amd.optim import FusedAdamW
     torch.manual_seed(0)
     mae = MAE(MASK_RATIO, PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH).to(dev).train()
-    ddp = GradAllReduce(mae) if world > 1 else None
+    ddp = GradAllReduce(mae, comm_dtype=torch.bfloat16 if comm_dtype == "bf16" else torch.float32) if world > 1 else None
     opt = FusedAdamW(mae.parameters(), lr=1.5e-4, betas=(0.9, 0.95), weight_decay=0.05)
     g = torch.Generator().manual_seed(2000 + rank)
     imgs = [torch.rand(1, height, width, generator=g).to(dev) for _ in range(batch)]
@@ -244,7 +263,8 @@ def bench_mae(dev, rank, world, dist, batch, height, width, steps, dtype, want_c
     step_flops = 3 * flops_mae_fwd(n) * batch          # forward + backward ~ 3 x forward (2.29 TFLOP per 512x2048 image)
     ms = dt / steps * 1e3
     out = dict(images_per_s=world * batch * steps / dt, ms_per_step=ms, batch_per_gpu=batch, image=f"{height}x{width}", dtype=dtype, steps=steps,
-               includes="forward + MAELoss + backward" + (" + RCCL gradient all-reduce" if world > 1 else "") + " + fused AdamW step",
+               includes="forward + MAELoss + backward" + _allreduce_label(dist if world > 1 else None) + " + fused AdamW step",
+               grad_comm_dtype=comm_dtype if world > 1 else None,
                loss=float(loss.detach()), tflops_algorithmic=step_flops / (ms * 1e-3) / 1e12)
     del opt, ddp
     # dominant kernels by time: the d_h = 32 self-attention of the 8-layer MAE decoder over all n patches, timed live exactly as the step issues
@@ -362,7 +382,7 @@ def bench_ragged_decode(dev, steps, warm=16):
 
 
 # ---- config 5: data-parallel MAE + teacher-forced steps on ragged shards ---------------------------------------------------------------------
-def bench_config5(dev, rank, world, dist, per_gpu, T, steps):
+def bench_config5(dev, rank, world, dist, per_gpu, T, steps, comm_dtype="fp32"):
     """Global batch of per_gpu * world ragged images (the 8 config-4 shapes, repeated) dealt to the ranks by patch count (`shard_by_cost`),
     one DP MAE step (fwd + loss + bwd + gradient all-reduce + AdamW) and one DP teacher-forced step (forward_train + CE + bwd + all-reduce +
     AdamW over the LLRD groups).  `allreduce_exposed_ms` = time the compute stream spends in `GradAllReduce.finish()` per step (HIP events):
@@ -393,7 +413,9 @@ def bench_config5(dev, rank, world, dist, per_gpu, T, steps):
     # MAE
     torch.manual_seed(0)
     mae = MAE(MASK_RATIO, PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH).to(dev).train()
-    ddp = GradAllReduce(mae)
+    cdt = torch.bfloat16 if comm_dtype == "bf16" else torch.float32
+    wire = 2 if comm_dtype == "bf16" else 4
+    ddp = GradAllReduce(mae, comm_dtype=cdt)
     opt = FusedAdamW(mae.parameters(), lr=1.5e-4, betas=(0.9, 0.95), weight_decay=0.05)
     data = list(zip(imgs, imgs))
     evs = []
@@ -412,7 +434,8 @@ def bench_config5(dev, rank, world, dist, per_gpu, T, steps):
     torch.cuda.synchronize()
     out["mae"] = dict(ms_per_step=dt / steps * 1e3, images_per_s=per_gpu * world * steps / dt,
                       allreduce_exposed_ms=sum(a.elapsed_time(b) for a, b in evs[-steps:]) / steps,
-                      grad_bytes=sum(p.numel() for p in mae.parameters() if p.requires_grad) * 4)
+                      grad_bytes=sum(p.numel() for p in mae.parameters() if p.requires_grad) * 4,
+                      grad_bytes_on_wire=sum(p.numel() for p in mae.parameters() if p.requires_grad) * wire, grad_comm_dtype=comm_dtype)
     del mae, ddp, opt, data
     torch.cuda.empty_cache()
     # teacher-forced
@@ -420,7 +443,7 @@ def bench_config5(dev, rank, world, dist, per_gpu, T, steps):
     enc = FineTuneOMREncoder(PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH, ENCODER_FINE_TUNE_DEPTH, transformer_dropout=0.0)
     dec = OMRDecoder(MAX_LMX_SEQ_LEN, os.path.join(ROOT, "lmx_vocab.txt"), num_layers=NUM_DECODER_LAYERS, transformer_dropout=0.0)
     m = ScheduledSamplingViTOMR(enc, None, dec, transition_head_dropout=0.0).to(dev).train()
-    ddp = GradAllReduce(m)
+    ddp = GradAllReduce(m, comm_dtype=cdt)
     groups, _ = m.create_fine_tune_param_groups(1e-4, 1e-5, 0.9)
     opt = FusedAdamW(groups, betas=(0.9, 0.95), weight_decay=0.01)
     loss_fn = OMRCELoss(dec.pad_idx)
@@ -441,11 +464,12 @@ def bench_config5(dev, rank, world, dist, per_gpu, T, steps):
     torch.cuda.synchronize()
     out["tf_step"] = dict(ms_per_step=dt / steps * 1e3, images_per_s=per_gpu * world * steps / dt,
                           allreduce_exposed_ms=sum(a.elapsed_time(b) for a, b in evs[-steps:]) / steps,
-                          grad_bytes=sum(p.numel() for p in m.parameters() if p.requires_grad) * 4)
+                          grad_bytes=sum(p.numel() for p in m.parameters() if p.requires_grad) * 4,
+                          grad_bytes_on_wire=sum(p.numel() for p in m.parameters() if p.requires_grad) * wire, grad_comm_dtype=comm_dtype)
     del m, ddp, opt, data, enc, dec
     torch.cuda.empty_cache()
     out["dp_parity_max_abs_diff"] = dp_parity_check(os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "lmx_vocab.txt"), dev)
-    out["dp_parity_ok"] = bool(out["dp_parity_max_abs_diff"] < 1e-4)   # DP step over RCCL == the single-process global-batch step
+    out["dp_parity_ok"] = bool(out["dp_parity_max_abs_diff"] < 1e-4)   # DP step (fp32 buckets) over the process group == the single-process global-batch step
     if not out["dp_parity_ok"]:
         out["error"] = f"data-parallel step differs from the single-process global-batch step by {out['dp_parity_max_abs_diff']:.3e} (>= 1e-4)"
     return out
@@ -533,8 +557,11 @@ def dry_run(a):
     dev = torch.device("cpu")
     legs = set((a.legs.split(",") if a.legs is not None else (["e2e", "b1", "mae", "tf", "ragged"] if world == 1 else ["mae", "config5"])))
     legs.discard("")
+    if a.legs is None:
+        assert legs == ({"e2e", "b1", "mae", "tf", "ragged"} if world == 1 else {"mae", "config5"}), legs   # what the driver's N = 1, 2, 4, 8 runs select
     if a.no_mae:
         legs.discard("mae")
+    dinfo = dist_info(dist, dev, None)
 
     def sync():
         if dist is not None:
@@ -559,10 +586,12 @@ def dry_run(a):
                ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic", dry_run=True,
                config=dict(workload=f"DRY RUN (no kernels): vitomr_greedy_decode batch {a.batch}/GPU of {a.height}x{a.width} images ({S} patches)", batch_per_gpu=a.batch,
                            memory_len=S, decoder="12 x d1024 h16 mlp4096, V=227", hipgraph=True),
-               roofline=None, cpu_baseline=None, mae=None, tf_step=None, ragged_decode=None, config5=None, end_to_end=None, latency_b1=None)
+               roofline=None, cpu_baseline=None, mae=None, tf_step=None, ragged_decode=None, config5=None, end_to_end=None, latency_b1=None, dist=dinfo,
+               value_steps256=None)
     if "mae" in legs:
         d = timed(lambda: time.sleep(1e-4), a.mae_steps)
-        out["mae"] = dict(images_per_s=world * a.mae_batch * a.mae_steps / d, ms_per_step=d / a.mae_steps * 1e3, batch_per_gpu=a.mae_batch, dtype=a.mae_dtype, dry_run=True)
+        out["mae"] = dict(images_per_s=world * a.mae_batch * a.mae_steps / d, ms_per_step=d / a.mae_steps * 1e3, batch_per_gpu=a.mae_batch, dtype=a.mae_dtype, dry_run=True,
+                          includes="forward + MAELoss + backward" + _allreduce_label(dist) + " + fused AdamW step", grad_comm_dtype=a.grad_comm_dtype if world > 1 else None)
     for key, name in (("tf", "tf_step"), ("ragged", "ragged_decode"), ("e2e", "end_to_end"), ("b1", "latency_b1")):
         if key in legs and world == 1:
             out[name] = dict(dry_run=True)
@@ -578,7 +607,10 @@ def dry_run(a):
             dist.all_reduce(tot)      # the local / global count fractions of all ranks sum to one
         out["config5"] = dict(config=f"DRY RUN: global batch {32 * world} ragged images dealt by cost, {len(mine)} on rank 0 ({sum(costs[i] for i in mine)} patches)",
                               images_global=32 * world, shard_sizes=[len(s) for s in shards], shard_patches=[sum(costs[i] for i in s) for s in shards],
-                              count_fractions_sum=float(tot.item()), mae=dict(dry_run=True), tf_step=dict(dry_run=True), dp_parity_max_abs_diff=None, dp_parity_ok=None)
+                              count_fractions_sum=float(tot.item()),
+                              mae=dict(dry_run=True, ms_per_step=None, images_per_s=None, allreduce_exposed_ms=None, grad_bytes=None, grad_bytes_on_wire=None, grad_comm_dtype=a.grad_comm_dtype),
+                              tf_step=dict(dry_run=True, ms_per_step=None, images_per_s=None, allreduce_exposed_ms=None, grad_bytes=None, grad_bytes_on_wire=None, grad_comm_dtype=a.grad_comm_dtype),
+                              dp_parity_max_abs_diff=None, dp_parity_ok=None)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
@@ -602,6 +634,7 @@ def main():
     ap.add_argument("--mae-dtype", default="bf16", choices=["fp32", "bf16"])
     ap.add_argument("--legs", default=None, help="comma list of e2e,b1,mae,tf,ragged,config5 (default: e2e,b1,mae,tf,ragged at N = 1; mae,config5 at N > 1)")
     ap.add_argument("--no-mae", action="store_true")
+    ap.add_argument("--grad-comm-dtype", default="fp32", choices=["fp32", "bf16"], help="what the gradient buckets travel as at N > 1 (dist.GradAllReduce comm_dtype)")
     ap.add_argument("--leg-timeout", type=float, default=420.0, help="seconds the secondary legs may take before the line is printed without them")
     ap.add_argument("--dry-run", action="store_true", help="control flow only, on the CPU over gloo: argument parsing, rank / leg selection, the collectives "
                     "around the timed regions and the JSON line's shape, with stand-in numbers (no kernel runs; `dry_run: true` marks the line)")
@@ -626,6 +659,7 @@ def main():
     legs.discard("")
     if a.no_mae:
         legs.discard("mae")
+    dinfo = dist_info(dist, dev, None)
 
     from torch.amp import autocast
     vitomr = build_model(dev, a.batch)
@@ -677,8 +711,18 @@ def main():
         run_steps(a.steps)
         _barrier_sync(dist)
         dt = time.perf_counter() - t0
+        # the same region over 256 steps (0.2 s): the driver's --steps 20 times 14 ms, this side field says what a longer window gives
+        dt256 = None
+        if a.steps != 256:
+            _barrier_sync(dist)
+            t1 = time.perf_counter()
+            run_steps(256)
+            _barrier_sync(dist)
+            dt256 = time.perf_counter() - t1
     cur.wait_stream(eng.stream)
     dt = _max_over_ranks(dt, dist, dev)
+    if dt256 is not None:
+        dt256 = _max_over_ranks(dt256, dist, dev)
     tokens = world * a.batch * a.steps
     assert int(eng.step[0].item()) == 1 + pos  # every replay advanced the device-side position
 
@@ -750,7 +794,8 @@ def main():
                    config=dict(workload=f"vitomr_greedy_decode batch {a.batch}/GPU of {a.height}x{a.width} images ({S} patches), decode steps {a.warmup + 1}..{a.warmup + a.steps}" + ("" if a.warmup + a.steps <= cap else f" (re-armed every {cap} steps)"),
                                batch_per_gpu=a.batch, memory_len=S, decoder="12 x d1024 h16 mlp4096, V=227", hipgraph=True),
                    prefill_ms=prefill_s * 1e3, prefill_encoder_dtype=a.encoder_dtype, roofline=roof, cpu_baseline=cpu, mae=mae_res, tf_step=tf_res,
-                   ragged_decode=rag_res, config5=c5_res)
+                   ragged_decode=rag_res, config5=c5_res, dist=dinfo,
+                   value_steps256=(tokens / dt if a.steps == 256 else world * a.batch * 256 / dt256))
         if timed_out:
             out["legs_timed_out"] = f"secondary legs did not finish within {a.leg_timeout} s; fields still None were not measured"
         # decode-only (`value`) and end to end.  `end_to_end` = a TIMED call of inference() on the same batch shape (encoder + head +
@@ -774,13 +819,13 @@ def main():
     if "b1" in legs and world == 1:
         run_leg("latency_b1", bench_inference_call, dev, [(256, 1024)], 256, 3, want_cpu)
     if "mae" in legs:
-        run_leg("mae", bench_mae, dev, rank, world, dist, a.mae_batch, a.height, a.width, a.mae_steps, a.mae_dtype, want_cpu)
+        run_leg("mae", bench_mae, dev, rank, world, dist, a.mae_batch, a.height, a.width, a.mae_steps, a.mae_dtype, want_cpu, a.grad_comm_dtype)
     if "tf" in legs and world == 1:
         run_leg("tf_step", bench_tf_step, dev, 16, a.height, a.width, 512, 2)
     if "ragged" in legs and world == 1:
         run_leg("ragged_decode", bench_ragged_decode, dev, 512)
     if "config5" in legs:
-        run_leg("config5", bench_config5, dev, rank, world, dist, 32, 512, 2)
+        run_leg("config5", bench_config5, dev, rank, world, dist, 32, 512, 2, a.grad_comm_dtype)
     running[0] = "-"
     emit(False)
     if dist is not None:

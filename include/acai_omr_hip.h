@@ -249,7 +249,12 @@ int acai_decode_embed(const AcaiDecoder *dec, void *stream);
  * capture it in a hipGraph and replay.
  * CONTRACT (E % 4 == 0): the step does NOT embed its own input - dec->x must hold it: written by acai_decode_embed after arming, and by every
  * step's argmax / sampling kernel for the next one.  acai_decode_logits and acai_decode_hidden overwrite dec->x: after either, call
- * acai_decode_embed again before the next acai_decode_step / acai_decode_sample_step (the Python engine tracks this itself). */
+ * acai_decode_embed again before the next acai_decode_step / acai_decode_sample_step.  ENFORCED since round 4: the library records per
+ * decoder state (keyed by dec->x) whether x holds a chained step's input - set by acai_decode_embed, kept by the step entry points, cleared
+ * by acai_decode_logits / acai_decode_hidden - and acai_decode_step / acai_decode_sample_step return an argument error (rc < 0,
+ * acai_last_error() names acai_decode_embed) when it does not.  Replays of a captured graph do not pass through the check.
+ * tickets: the in-launch merge is used only while decode_attn_kernel's residency is the one it was validated at (two workgroups per CU,
+ * hipOccupancyMaxActiveBlocksPerMultiprocessor); otherwise the step issues the separate combine launch as if tickets were NULL. */
 int acai_decode_step(const AcaiDecoder *dec, void *stream);
 /* One SAMPLING decode step for every sequence (GRPOViTOMR.cached_forward_rollout_policy, acai_omr/models/models.py:988-1049): as
  * acai_decode_step, but the next token is drawn from softmax(top_k(logits) / temperature) and its log-probability is taken under

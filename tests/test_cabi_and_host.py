@@ -176,3 +176,26 @@ def test_cu_seqlens_are_cached_per_lengths_and_uploads_pass_cpu_through():
     assert engine.cu_from_lens((3, 5, 1), "cpu") is a and engine.cu_from_lens([3, 5, 2], "cpu") is not a
     t = torch.arange(6, dtype=torch.int64)
     assert ops.h2d(t, "cpu") is t and ops.h2d(t, "cpu", torch.int32).dtype == torch.int32
+
+
+def test_asm_checks_flag_what_they_are_for():
+    """acai_omr_amd/_asmcheck.py runs inside _lib.build() and fails the build: (1) a register written by an inline-asm load the compiler cannot
+    see, touched before the kernel's counted vmcnt wait (the miscompile gemm_nt_pp_kernel once hit); (2) more LDS operations behind the staged
+    tiles' stores than attn_fwd64w_kernel's counted tile barrier allows.  Doctored snippets: the clean form passes, the broken form is named."""
+    from acai_omr_amd import _asmcheck
+    head = "_ZN12_GLOBAL__N_117gemm_nt_pp_kernelItLi1EEEvNS_8GemmArgsE:\n"
+    clean = head + "\t;;#ASMSTART\n\tglobal_load_dword v7, v3, s[2:3]\n\t;;#ASMEND\n\tv_add_f32 v1, v2, v3\n\ts_waitcnt vmcnt(4)\n\tv_mov_b32 v9, v7\n\ts_endpgm\n"
+    broken = head + "\t;;#ASMSTART\n\tglobal_load_dword v7, v3, s[2:3]\n\t;;#ASMEND\n\tv_mov_b32 v9, v7\n\ts_waitcnt vmcnt(4)\n\ts_endpgm\n"
+    tracked = head + "\tglobal_load_dword v7, v3, s[2:3]\n\tv_mov_b32 v9, v7\n\ts_endpgm\n"     # a compiler-issued load: its own wait counts cover it
+    assert _asmcheck.check_untracked_loads(clean) == ([], 1)
+    p, n = _asmcheck.check_untracked_loads(broken)
+    assert n == 1 and len(p) == 1 and "v_mov_b32 v9, v7" in p[0]
+    assert _asmcheck.check_untracked_loads(tracked) == ([], 0)
+    whead = "_ZN12_GLOBAL__N_118attn_fwd64w_kernelILi0EEEv8AttnArgs:\n"
+    reads = "".join(f"\tds_read_b64_tr_b16 v[{2 * i}:{2 * i + 1}], v100\n" for i in range(4))
+    ok = whead + "\tds_write_b128 v1, v[2:5]\n" + reads + "\ts_waitcnt lgkmcnt(4)\n\ts_barrier\n\ts_endpgm\n"
+    bad = whead + "\tds_write_b128 v1, v[2:5]\n" + reads + "\tds_read_b128 v[20:23], v101\n\ts_waitcnt lgkmcnt(4)\n\ts_barrier\n\ts_endpgm\n"
+    assert _asmcheck.check_fwd64w_barrier(ok) == ([], 1)
+    p, n = _asmcheck.check_fwd64w_barrier(bad)
+    assert n == 1 and len(p) == 1 and "5 LDS operations" in p[0]
+    assert _asmcheck.check_fwd64w_barrier("nothing here\n")[0]      # the kernel vanished: that is a finding too

@@ -21,7 +21,7 @@ def _masked_mean_loss(model, x, mask):
     return (per_row * mask).sum(), mask.sum()
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, comm="float32"):
     sys.path.insert(0, ROOT)
     from acai_omr_amd.dist import GradAllReduce, global_mean_scale
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -31,7 +31,7 @@ def _worker(rank, world, port, out):
     M = (torch.rand(10, generator=g) > 0.4).float()
     shard = slice(0, 7) if rank == 0 else slice(7, 10)   # ragged shards: 7 vs 3 rows, different masked counts
     model = _model()
-    ddp = GradAllReduce(model, bucket_mb=0.0002)          # tiny buckets -> several all-reduces
+    ddp = GradAllReduce(model, bucket_mb=0.0002, comm_dtype=getattr(torch, comm))          # tiny buckets -> several all-reduces
     assert len(ddp.buckets) >= 3
     # one step, global-count normalisation
     ddp.zero_grad()
@@ -55,10 +55,16 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_grad_allreduce_matches_single_process_global_batch(tmp_path):
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("comm", ["float32", "bfloat16"])
+def test_grad_allreduce_matches_single_process_global_batch(tmp_path, comm):
+    """comm = bfloat16: the buckets travel as bf16 (half the bytes over xGMI) and are widened back into the fp32 buckets - the cross-rank sum is
+    rounded to bf16, local accumulation (the no_sync micro-batches) stays fp32."""
     out = str(tmp_path / "g.pt")
-    port = 29500 + os.getpid() % 2000
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    port = 29500 + os.getpid() % 2000 + (7 if comm == "bfloat16" else 0)
+    mp.spawn(_worker, args=(2, port, out, comm), nprocs=2, join=True)
     g1, g2 = torch.load(out)
     g = torch.Generator().manual_seed(1)
     X = torch.randn(10, 6, generator=g)
@@ -67,12 +73,16 @@ def test_grad_allreduce_matches_single_process_global_batch(tmp_path):
     s, c = _masked_mean_loss(model, X, M)
     (s / c).backward()
     ref1 = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
-    assert torch.allclose(g1, ref1, atol=1e-6)          # DP == single-process global batch
+    # bf16 buckets: each rank's addend and the sum are rounded to 8 significant bits
+    tol1, tol2 = (1e-6, 1e-5) if comm == "float32" else (2e-2 * float(ref1.abs().max()), None)
+    assert torch.allclose(g1, ref1, atol=tol1)          # DP == single-process global batch
     model.zero_grad()
     s, _ = _masked_mean_loss(model, X, M)
     s.backward()
     ref2 = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
-    assert torch.allclose(g2, ref2, atol=1e-5)          # accumulated sums, one sync
+    assert torch.allclose(g2, ref2, atol=tol2 if tol2 is not None else 2e-2 * float(ref2.abs().max()))          # accumulated sums, one sync
+    if comm == "bfloat16":
+        assert not torch.equal(g1, ref1)                # (the rounding really happened: the mode is not silently fp32)
 
 
 def test_shard_by_cost_balances_ragged_batch():
@@ -248,6 +258,51 @@ def test_parameter_without_gradient_on_one_rank_stays_in_step(tmp_path):
     assert torch.equal(r0, r1)
 
 
+def _worker_unused_everywhere(rank, world, port, out):
+    """A parameter NO rank produces a gradient for (a frozen-by-construction branch): it must keep .grad = None and stay out of the AdamW step
+    on every rank, exactly as in the single-process global-batch step; one that only rank 0 touches is stepped on both."""
+    sys.path.insert(0, ROOT)
+    from acai_omr_amd.dist import GradAllReduce
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    a, b, c = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)
+    model = torch.nn.ModuleList([a, b, c])
+    ddp = GradAllReduce(model, bucket_mb=0.00005)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, weight_decay=0.1)
+    x = torch.ones(3, 4) * (rank + 1)
+    c0 = [p.detach().clone() for p in c.parameters()]
+    none_ok = True
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        y = a(x).sum() + (b(x).sum() if rank == 0 else 0.0)    # c: never
+        y.backward()
+        ddp.finish()
+        none_ok &= all(p.grad is None for p in c.parameters()) and all(p.grad is not None for p in list(a.parameters()) + list(b.parameters()))
+        opt.step()
+    untouched = all(torch.equal(p.detach(), q) for p, q in zip(c.parameters(), c0))    # no weight decay, no step count
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    ok = torch.tensor([float(none_ok and untouched)])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        torch.save((gathered, bool(ok.item() > 0)), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_parameter_without_gradient_on_every_rank_keeps_none(tmp_path):
+    """finish() used to hand a globally unused parameter an all-zero .grad, so AdamW applied weight decay / moment decay / a step
+    count to it that the single-process step skips.  The per-parameter "some rank had a gradient" flags that ride at the end of the last
+    bucket now decide: unused everywhere -> .grad stays None on every rank."""
+    out = str(tmp_path / "ue.pt")
+    port = 35500 + os.getpid() % 2000
+    mp.spawn(_worker_unused_everywhere, args=(2, port, out), nprocs=2, join=True)
+    (r0, r1), ok = torch.load(out)
+    assert ok and torch.equal(r0, r1)
+
+
 def test_bench_dry_run_two_ranks():
     """`bench.py --gpus 2 --dry-run` under torch.distributed.run (gloo, CPU): the launcher contract, the leg selection at N > 1 and the JSON
     line's keys, incl. config 5's shard deal - what the driver's first multi-GPU run exercises around the kernels."""
@@ -270,8 +325,33 @@ def test_bench_dry_run_two_ranks():
     c5 = d["config5"]
     assert c5["images_global"] == 64 and c5["shard_sizes"] == [32, 32] and abs(c5["count_fractions_sum"] - 1.0) < 1e-12
     assert abs(c5["shard_patches"][0] - c5["shard_patches"][1]) <= 1024   # cost-balanced deal of the ragged shapes
+    # the line says what it ran on: backend as torch reports it, the world size it saw, one device entry per rank - and never "RCCL" under gloo
+    assert d["dist"]["backend"] == "gloo" and d["dist"]["world_size"] == 2 and len(d["dist"]["devices"]) == 2 and "rehearsal" in d["dist"]["transport"]
+    assert "RCCL gradient" not in d["mae"]["includes"] and "gloo gradient all-reduce" in d["mae"]["includes"]
+    for leg in ("mae", "tf_step"):
+        assert "allreduce_exposed_ms" in c5[leg] and "grad_bytes_on_wire" in c5[leg] and c5[leg]["grad_comm_dtype"] == "fp32"
     # and the single-process form selects the single-GPU legs
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "3"], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
     assert r1.returncode == 0, r1.stderr[-2000:]
     d1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
     assert d1["n_gpus"] == 1 and d1["config5"] is None and d1["end_to_end"] is not None and d1["latency_b1"] is not None and d1["tf_step"] is not None
+
+
+def test_bench_dry_run_eight_ranks_selects_the_multi_gpu_legs():
+    """The driver's N = 8 launch, rehearsed on the CPU (8 gloo ranks): default legs = mae + config5 (asserted inside --dry-run), the config-5 keys
+    the scaling record will be read from, the bf16 bucket option on the command line, 8 device entries."""
+    import json
+    import subprocess
+    port = 37500 + os.getpid() % 2000
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port",
+                        str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--dry-run", "--grad-comm-dtype", "bf16"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 8 and d["dist"]["world_size"] == 8 and len(d["dist"]["devices"]) == 8
+    assert d["mae"] is not None and d["config5"] is not None and d["tf_step"] is None and d["end_to_end"] is None
+    c5 = d["config5"]
+    assert c5["images_global"] == 256 and c5["shard_sizes"] == [32] * 8 and max(c5["shard_patches"]) - min(c5["shard_patches"]) <= 1024
+    for leg in ("mae", "tf_step"):
+        assert "allreduce_exposed_ms" in c5[leg] and c5[leg]["grad_comm_dtype"] == "bf16"

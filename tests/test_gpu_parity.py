@@ -600,3 +600,60 @@ def test_chained_steps_after_a_stepwise_call_reembed_their_input(dev):
     n = ref.shape[1]
     live = m.create_inference_mask(got)[:, :n]
     assert torch.equal(got[:, :n].masked_fill(~live, m.decoder.pad_idx).cpu(), ref.cpu())
+
+
+def test_c_abi_refuses_a_chained_step_on_a_stale_input(dev):
+    """the chained-decode contract ("x must hold step t's embedding") lived in engine.py only; a C-ABI caller that mixed
+    acai_decode_logits (which overwrites x) with acai_decode_step got a step on stale input and rc 0.  The library now keeps the marker itself:
+    step after logits -> argument error with a message that names the remedy; after acai_decode_embed the step runs."""
+    import ctypes
+
+    from acai_omr_amd import _lib, ops
+    from acai_omr_amd import engine as EG
+    fx = load_golden("vitomr_small")
+    cfg = fx["cfg"]
+    m = build_vitomr(cfg, fx["state_dict"], dev, torch.float)
+    L = _lib.lib()
+    with torch.no_grad():
+        lat, mask = m.encoder(fx["imgs"])
+        mem = m.transition_head(lat)
+        blocks = m.decoder.decoder_blocks
+        packed, lens = EG.unpad_rows(mem, mask)
+        blocks.prepare_caches_packed(packed, None, lens)
+        eng = blocks.engine(packed.device)
+        with torch.cuda.stream(eng.stream):
+            eng.arm(eng.B)                       # acai_decode_embed: marker set
+            st = ops._st()
+            assert L.acai_decode_step(ctypes.byref(eng._desc), st) == 0
+            tok = torch.full((eng.B,), 5, dtype=torch.int64, device=dev)
+            assert L.acai_decode_logits(ctypes.byref(eng._desc), tok.data_ptr(), 2, st) == 0     # overwrites x: marker cleared
+            rc = L.acai_decode_step(ctypes.byref(eng._desc), st)
+            assert rc != 0 and b"acai_decode_embed" in L.acai_last_error()
+            assert L.acai_decode_hidden(ctypes.byref(eng._desc), eng.ws["x"].data_ptr(), st) == 0
+            assert L.acai_decode_step(ctypes.byref(eng._desc), st) != 0
+            assert L.acai_decode_embed(ctypes.byref(eng._desc), st) == 0
+            assert L.acai_decode_step(ctypes.byref(eng._desc), st) == 0
+            torch.cuda.synchronize()
+
+
+def test_in_launch_merge_is_selected_only_at_its_validated_residency(dev):
+    """the split partials are merged inside the attention launch only while decode_attn_kernel's residency is the one the
+    hand-off was validated at (two workgroups per CU); ACAI_DATTN_MERGE forces either path.  Both paths give the same tokens."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import torch, sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests'); from test_gpu_parity import load_golden, build_vitomr\n"
+            "fx = load_golden('vitomr_dh64b'); cfg = fx['cfg']; m = build_vitomr(cfg, fx['state_dict'], torch.device('cuda:0'), torch.bfloat16)\n"
+            "from acai_omr_amd.inference.vitomr_inference import inference\n"
+            "seqs, lps, mask = inference(m, fx['imgs'], 'cuda', max_inference_len=cfg['gen_len']); print('TOK', seqs.cpu().tolist())\n") % (ROOT, ROOT)
+    outs = []
+    for force in ("0", "1", None):
+        env = dict(os.environ)
+        env.pop("ACAI_DATTN_MERGE", None)
+        if force is not None:
+            env["ACAI_DATTN_MERGE"] = force
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("TOK")][0])
+    assert outs[0] == outs[1] == outs[2]

@@ -1,4 +1,6 @@
-"""Timing ablations of gemm_nt_pp_kernel (variant 7) through ACAI_GEMM_DEBUG bits (results are wrong in these modes; timing only):
+"""Timing ablations of gemm_nt_pp_kernel (variant 7) through ACAI_GEMM_DEBUG bits (results are wrong in these modes; timing only).  The bits exist in
+-DACAI_GEMM_ABLATE builds only: bash tools/build_variant.sh ablpp "-DACAI_GEMM_ABLATE" gemm.hip; ACAI_OMR_LIB=.../variants/ablpp.so python tools/ablate_pp.py
+Bits:
 1 no counted DMA waits, 2 no LDS-DMA issue, 4 no epilogue, 8 no MFMAs, 16 no fragment reads."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
