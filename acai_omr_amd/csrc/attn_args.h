@@ -14,7 +14,7 @@ struct AttnArgs {
     float *lse;   // optional [H][total_q]: log2-domain log-sum-exp of the scaled scores (saved for the backward pass)
     int total_q;
     int nqb;      // attn_fwd64w.hip: query blocks per (sequence, head) of its one-dimensional, XCD-swizzled grid
-    int tail;     // attn_fwd64*.hip: 1 = a sequence's last 256-query block goes to the 128-query kernel's tail launch when it holds <= 128 rows
+    int tail;     // attn_fwd64*.hip: > 0 = a sequence's last 256-query block goes to attn_fwd64_tail_kernel when it holds <= tail (32) rows
 };
 
 // bf16, d_h = 64 exactly, q prescaled, no dropout, no causal mask, 16-byte aligned operands (attn_fwd64.hip)

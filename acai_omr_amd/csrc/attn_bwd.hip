@@ -139,9 +139,9 @@ template <typename T, int DHP, bool FAST>
 struct TileStager {
     typedef TileLayout<sizeof(T), DHP> TL;
     static constexpr int ES = sizeof(T), EPC = 16 / ES, RP = TL::PITCH, CPR = DHP / EPC, NCH = 64 * CPR / 256;
-    const T *pa[NCH], *pb[NCH], *A, *B;
+    const T *A, *B;
     int srow[NCH], soff[NCH], lda, ldb, dh;
-    bool dok[NCH];
+    uint32_t ga[NCH], gb[NCH];   // FAST: this thread's byte offsets inside a tile (beyond every resource for chunks past d_h)
     uint4 ra[NCH], rb[NCH];
     __device__ __forceinline__ void init(const T *A_, int lda_, const T *B_, int ldb_, int tid, int dh_, int first_tile) {
         A = A_; B = B_; lda = lda_; ldb = ldb_; dh = dh_;
@@ -150,24 +150,26 @@ struct TileStager {
             const int c = tid + 256 * i, row = c / CPR, cc = c % CPR;
             srow[i] = row;
             soff[i] = TL::off(row, cc);
-            dok[i] = cc * EPC < dh;
-            pa[i] = A + ((size_t)first_tile * 64 + row) * lda + cc * EPC;
-            pb[i] = B + ((size_t)first_tile * 64 + row) * ldb + cc * EPC;
+            const bool dok = cc * EPC < dh;
+            ga[i] = dok ? (uint32_t)((row * lda + cc * EPC) * ES) : 0xFFFFFFF0u;
+            gb[i] = dok ? (uint32_t)((row * ldb + cc * EPC) * ES) : 0xFFFFFFF0u;
         }
     }
-    // tiles must be requested in increasing order, one call per tile (the pointers advance)
+    // FAST (round 4): buffer loads through a resource rebuilt per tile in SGPRs - base = the tile's first row, num_records = the rows that exist
+    // (only the VGPR offset is range-checked) - so rows past the sequence end and chunks past d_h read as zeros with no exec-mask branch, no
+    // v_cndmask and no 64-bit pointer arithmetic per tile (the guarded global loads cost ~40 VALU / SALU instructions per tile on loops that
+    // have no issue slots to spare).  The host checks that an operand's rows x pitch fits the 32-bit num_records.
     __device__ __forceinline__ void load(int t, int rows) {
         if constexpr (FAST) {
-            const bool full = (t + 1) * 64 <= rows;
+            const int left = rows - t * 64;
+            const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(A + (size_t)t * 64 * lda), 0, left > 0 ? left * lda * ES : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(B + (size_t)t * 64 * ldb), 0, left > 0 ? left * ldb * ES : 0, 0x00020000);
+            typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
-                ra[i] = rb[i] = make_uint4(0, 0, 0, 0);
-                if (dok[i] && (full || t * 64 + srow[i] < rows)) {
-                    ra[i] = *reinterpret_cast<const uint4 *>(pa[i]);
-                    rb[i] = *reinterpret_cast<const uint4 *>(pb[i]);
-                }
-                pa[i] += (size_t)64 * lda;
-                pb[i] += (size_t)64 * ldb;
+                const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rsa, ga[i], 0, 0), y = __builtin_amdgcn_raw_buffer_load_b128(rsb, gb[i], 0, 0);
+                ra[i] = make_uint4(x[0], x[1], x[2], x[3]);
+                rb[i] = make_uint4(y[0], y[1], y[2], y[3]);
             }
         } else {
 #pragma unroll
@@ -929,7 +931,8 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, bool pre, hipStrea
     constexpr int ES = sizeof(T), EPC = 16 / ES;
     const bool fast = (a.dh % EPC == 0) && (a.ldq % EPC == 0) && (a.ldk % EPC == 0) && (a.ldv % EPC == 0) && (a.lddo % EPC == 0) && (a.ldo % EPC == 0) &&
                       aligned16(a.q) && aligned16(a.k) && aligned16(a.v) && aligned16(a.dout) && aligned16(a.o) &&
-                      (a.lddq % EPC == 0) && (a.lddk % EPC == 0) && (a.lddv % EPC == 0) && aligned16(a.dq) && aligned16(a.dk) && aligned16(a.dv);   // vector stores of the gradients too
+                      (a.lddq % EPC == 0) && (a.lddk % EPC == 0) && (a.lddv % EPC == 0) && aligned16(a.dq) && aligned16(a.dk) && aligned16(a.dv) &&   // vector stores of the gradients too
+                      (size_t)max_q * (size_t)(a.ldq > a.lddo ? a.ldq : a.lddo) * ES < 0x7FFFFF00ull && (size_t)max_k * (size_t)(a.ldk > a.ldv ? a.ldk : a.ldv) * ES < 0x7FFFFF00ull;   // the staging's 32-bit buffer resources
     constexpr int RP = TileLayout<ES, DHP>::PITCH;
     const size_t lds_dq = 2 * (2 * TT * RP), lds_dkv = 2 * (2 * TT * RP + 2 * TT * sizeof(float));   // two stages each
     if (pre && !fast) return acai_set_err(-1, "acai_attn_varlen_bwd: q_prescaled needs 16-byte aligned operands and d_h %% %d == 0", EPC);

@@ -42,10 +42,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
     const int b = blockIdx.z, h = blockIdx.y;
     const int q_start = a.cu_q[b], lq = a.cu_q[b + 1] - q_start;
     const int k_start = a.cu_k[b], lk = a.cu_k[b + 1] - k_start;
-    // tail launch (a.tail): only the sequence's last, partial 256-query block when it holds <= 128 rows - what attn_fwd64w_kernel leaves
-    const int qbase = a.tail ? (lq / 256) * 256 : 0;
-    if (a.tail && (lq == qbase || lq - qbase > 128)) return;
-    const int q0 = qbase + blockIdx.x * QBG;
+    const int q0 = blockIdx.x * QBG;
     if (q0 >= lq) return;
 
     const bf16_t *Q = reinterpret_cast<const bf16_t *>(a.q) + (size_t)q_start * a.ldq + h * 64;
@@ -310,6 +307,142 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
     }
 }
 
+// ---- query tails of <= 32 rows (the 513th token of the teacher-forced decoder stream: models.py:531-540, omr_teacher_force_train.py:25) -------
+// A sequence whose last 256-query block holds r <= 32 rows would occupy a whole CU of attn_fwd64w_kernel for the full key loop with one of its
+// four SIMDs at work (513 queries x 4096 keys: 245 us against 146 us at 512 queries, tools/bench_cross_train_attn.py).  Here the KEYS of such
+// a tail are split over the 8 waves of one workgroup instead: wave w takes tiles w, w + 8, ... through a wave-private LDS region (no
+// barrier in the loop), with an ordinary online softmax (running maximum per wave - a tail is not worth a restart path), and the eight
+// partial (m, l, O) triples meet in LDS at the end.  1/8 of the key loop per tail, 256 small workgroups for the decoder's 16 x 16 pairs.
+__global__ __launch_bounds__(512) void attn_fwd64_tail_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[8 * 2 * SLOT];   // per wave: K tile, V tile (16 KB); reused for the partial results
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q_start = a.cu_q[b], lq = a.cu_q[b + 1] - q_start;
+    const int k_start = a.cu_k[b], lk = a.cu_k[b + 1] - k_start;
+    const int qbase = (lq / 256) * 256, r = lq - qbase;
+    if (r == 0 || r > 32) return;   // (whole workgroup: no barrier has been reached)
+    const bf16_t *Q = reinterpret_cast<const bf16_t *>(a.q) + (size_t)q_start * a.ldq + h * 64;
+    const bf16_t *K = reinterpret_cast<const bf16_t *>(a.k) + (size_t)k_start * a.ldk + h * 64;
+    const bf16_t *V = reinterpret_cast<const bf16_t *>(a.v) + (size_t)k_start * a.ldv + h * 64;
+    bf16_t *O = reinterpret_cast<bf16_t *>(a.out) + (size_t)q_start * a.ldo + h * 64;
+    const int my_q = qbase + lr, nkt = (lk + KT - 1) / KT;
+    uint4 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = lr < r ? *reinterpret_cast<const uint4 *>(Q + (size_t)my_q * a.ldq + s * 16 + lh * 8) : make_uint4(0, 0, 0, 0);
+    unsigned char *ldsK = lds + wave * 2 * SLOT, *ldsV = ldsK + SLOT;
+    const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+    f32x16 oacc[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+    float m_run = -1.0e30f, l_run = 0.f;   // running maximum of the lane's query (log2 domain) and this lane-half's partial row sum
+    for (int t = wave; t < nkt; t += 8) {
+        const int rows = lk - t * KT;
+        const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(K + (size_t)t * KT * a.ldk), 0, rows * a.ldk * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(V + (size_t)t * KT * a.ldv), 0, rows * a.ldv * 2, 0x00020000);
+        u32x4 rk[8], rv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {   // one wave stages both 8 KB tiles: chunk c = lane + 64 i -> row c / 8, 16-byte chunk c % 8
+            const int c = lane + 64 * i, row = c >> 3, cc = c & 7;
+            rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rK, (uint32_t)(row * a.ldk * 2 + cc * 16), 0, 0);
+            rv[i] = __builtin_amdgcn_raw_buffer_load_b128(rV, (uint32_t)(row * a.ldv * 2 + cc * 16), 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i, off = TL::off(c >> 3, c & 7);
+            *reinterpret_cast<u32x4 *>(ldsK + off) = rk[i];
+            *reinterpret_cast<u32x4 *>(ldsV + off) = rv[i];
+        }
+        // (wave-private image: the wave's own LDS operations complete in order - no barrier between its stores and its reads, nor between
+        // this tile's reads and the next tile's stores)
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const uint4 kf = *reinterpret_cast<const uint4 *>(ldsK + TL::off(kb * 32 + lr, 2 * s + lh));
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[s]), sacc[kb], 0, 0, 0);
+            }
+        }
+        float tmax = -1.0e30f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = t * KT + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                sacc[kb][e] = key < lk ? sacc[kb][e] : -1.0e30f;
+                tmax = fmaxf(tmax, sacc[kb][e]);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m2 = fmaxf(m_run, tmax), alpha = fast_exp2(m_run - m2);   // (every tile holds at least one key: m2 is a real score)
+        m_run = m2;
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            uint32_t pf[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float p0 = fast_exp2(sacc[kb][2 * g] - m_run), p1 = fast_exp2(sacc[kb][2 * g + 1] - m_run);   // masked keys: 2^(-1e30) = 0
+                pf[g] = pack_bf16(p0, p1);
+                l_run += round_bf16(p0) + round_bf16(p1);   // the sum of what multiplies V, as the MFMA row sums of the main kernels
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const int vrow = kb * 32 + 16 * s2 + 4 * lh + (i16 >> 2), vchunk = d * 4 + 2 * g1 + ((i16 & 3) >> 1), vsub = 8 * (i16 & 1);
+                    union { s4 v[2]; uint4 u; } vf;
+                    vf.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(ldsV + TL::off(vrow, vchunk) + vsub));
+                    vf.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(ldsV + TL::off(vrow + 8, vchunk) + vsub));
+                    const uint4 pb = make_uint4(pf[4 * s2], pf[4 * s2 + 1], pf[4 * s2 + 2], pf[4 * s2 + 3]);
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf.u), __builtin_bit_cast(bf16x8, pb), oacc[d], 0, 0, 0);
+                }
+        }
+    }
+    // ---- the eight partial results meet in LDS: wave w's region holds O_w[q][d] (fp32, 8 KB), then m_w[q], l_w[q] ------------------------------
+    float *part = reinterpret_cast<float *>(ldsK);
+    const float l_w = l_run + __shfl_xor(l_run, 32);
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) part[lr * 64 + d * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh] = oacc[d][e];
+    if (lh == 0) {
+        part[2048 + lr] = m_run;
+        part[2048 + 32 + lr] = l_w;
+    }
+    __syncthreads();
+    const int q = tid >> 4, d0 = (tid & 15) * 4;   // 512 threads x 4 outputs
+    float m = -1.0e30f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) m = fmaxf(m, reinterpret_cast<const float *>(lds + w * 2 * SLOT)[2048 + q]);
+    float l = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const float *pw = reinterpret_cast<const float *>(lds + w * 2 * SLOT);
+        const float f = fast_exp2(pw[2048 + q] - m);   // a wave without tiles: m_w = -1e30, l_w = 0, O_w = 0 -> f * 0
+        l += f * pw[2048 + 32 + q];
+        const f32x4 ov = *reinterpret_cast<const f32x4 *>(pw + q * 64 + d0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += f * ov[e];
+    }
+    if (q < r) {
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        uint2 pk;
+        pk.x = pack_bf16(o[0] * inv, o[1] * inv);
+        pk.y = pack_bf16(o[2] * inv, o[3] * inv);
+        *reinterpret_cast<uint2 *>(O + (size_t)(qbase + q) * a.ldo + d0) = pk;
+        if (a.lse && d0 == 0) a.lse[(size_t)h * a.total_q + q_start + qbase + q] = m + log2f(l);
+    }
+}
+
 }  // namespace
 
 int acai_attn_fwd64_launch(const AttnArgs &a, int B, int max_q, hipStream_t st) {
@@ -327,11 +460,15 @@ int acai_attn_fwd64_launch(const AttnArgs &a, int B, int max_q, hipStream_t st) 
     static const int wide_env = getenv("ACAI_ATTN64_WIDE") ? atoi(getenv("ACAI_ATTN64_WIDE")) : 1;
     if (wide_env) {
         AttnArgs w = a;
-        // every sequence max_q long and max_q a multiple of 256: no tails (were the claim wrong, the wide kernel still covers every row)
-        const bool uniform = (long long)B * max_q == (long long)a.total_q && max_q % 256 == 0;
-        w.tail = uniform ? 0 : 1;
-        acai_attn_fwd64w_launch(w, B, max_q, st);
-        if (!uniform) hipLaunchKernelGGL((attn_fwd64_kernel<4>), dim3(1, a.H, B), dim3(256), 0, st, w);
+        // A sequence's last 256-query block goes to the tail kernel when it holds <= 32 rows.  When every sequence is max_q long (B * max_q rows
+        // in all) the host knows whether such a tail exists and launches only what is needed; were that reading of the arguments wrong, the
+        // wide kernel (tail = 0) still covers every row.
+        const bool all_equal = (long long)B * max_q == (long long)a.total_q;
+        const int rem = max_q % 256;
+        const bool need_tail = !all_equal || (rem > 0 && rem <= 32);
+        w.tail = need_tail ? 32 : 0;
+        if (!(all_equal && max_q <= 32)) acai_attn_fwd64w_launch(w, B, max_q, st);
+        if (need_tail) hipLaunchKernelGGL(attn_fwd64_tail_kernel, dim3(1, a.H, B), dim3(512), 0, st, w);
         return 0;
     }
     if (nw_env == 8)

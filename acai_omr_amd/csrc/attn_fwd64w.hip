@@ -67,7 +67,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int q_start = a.cu_q[b], lq = a.cu_q[b + 1] - q_start;
     const int k_start = a.cu_k[b], lk = a.cu_k[b + 1] - k_start;
     const int q0 = qb * QBG;
-    if (q0 >= lq || (a.tail && lq - q0 <= 128)) return;   // tail: a last block of <= 128 rows belongs to attn_fwd64_kernel's tail launch
+    if (q0 >= lq || (a.tail && lq - q0 <= a.tail)) return;   // a last block of <= a.tail (32) rows belongs to attn_fwd64_tail_kernel
 
     const bf16_t *Q = reinterpret_cast<const bf16_t *>(a.q) + (size_t)q_start * a.ldq + h * 64;
     const bf16_t *K = reinterpret_cast<const bf16_t *>(a.k) + (size_t)k_start * a.ldk + h * 64;

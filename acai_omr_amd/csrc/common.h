@@ -118,6 +118,15 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return fmaf(x, __builtin_amdgcn_exp2f(fmaf(x * x, -0.72134752044448170368f, -1.3257480647361593f)), phi);
 }
 
+// GELU and its derivative of the same argument through ONE h = Phi(-|x|): the forward epilogue of linear1 that also keeps gelu'(a) for the
+// backward pass (aux_mode 3) pays one more exp2 + 5 VALU on top of the GELU itself instead of a second polynomial.
+__device__ __forceinline__ void gelu_erf_both(float x, float &g, float &dg) {
+    const float h = acai_half_erfc_abs(x);
+    g = fmaf(-fabsf(x), h, __int_as_float(max(__float_as_int(x), 0)));
+    const float phi = x < 0.0f ? h : 1.0f - h;
+    dg = fmaf(x, __builtin_amdgcn_exp2f(fmaf(x * x, -0.72134752044448170368f, -1.3257480647361593f)), phi);
+}
+
 template <typename T> struct DT;
 template <> struct DT<float> {
     static constexpr int id = ACAI_F32;

@@ -28,6 +28,9 @@ struct GemmArgs {
     int ksplit;  // > 0: split-K over `ksplit` workgroups per tile, fp32 atomic accumulation into C (weight gradients: K = rows)
     // aux_mode 1: `aux` (dtype of C) also receives the pre-activation while C gets GELU of it (training forward keeps both);
     // aux_mode 2: C = round(acc) * gelu'(aux)  (the dX GEMM of linear2 applies the GELU derivative of the saved pre-activation)
+    // aux_mode 3 (round 4, what the training steps use): as 1, but `aux` receives gelu'(pre-activation) - the forward epilogue holds
+    //             Phi(-|a|) anyway - and aux_mode 4: C = round(acc) * aux, ONE multiply per element in the backward epilogue, which was
+    //             VALU-bound on the derivative (tools/ablate_gelu_grad.py)
     void *aux;
     int ldaux, aux_mode;
     // columns [0, scale_cols) of (A.W^T + bias) are multiplied by col_scale before rounding (the in-projection's q for the attention kernels)
@@ -89,13 +92,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&
                 if constexpr (EPI == 0) {
                     v *= cs;
                     if (do_round) v = round_bf16(v);
-                    if (g.aux_mode == 1) {
-                        if (g.out_dtype == ACAI_BF16) reinterpret_cast<bf16_t *>(g.aux)[(size_t)row * g.ldaux + col] = f2bf(v);
-                        else reinterpret_cast<float *>(g.aux)[(size_t)row * g.ldaux + col] = v;
-                    } else if (g.aux_mode == 2) {
+                    if (g.aux_mode == 1 || g.aux_mode == 3) {
+                        const float keep = g.aux_mode == 1 ? v : gelu_erf_grad(v);
+                        if (g.out_dtype == ACAI_BF16) reinterpret_cast<bf16_t *>(g.aux)[(size_t)row * g.ldaux + col] = f2bf(keep);
+                        else reinterpret_cast<float *>(g.aux)[(size_t)row * g.ldaux + col] = keep;
+                    } else if (g.aux_mode == 2 || g.aux_mode == 4) {
                         const float a0 = g.out_dtype == ACAI_BF16 ? bf2f(reinterpret_cast<const bf16_t *>(g.aux)[(size_t)row * g.ldaux + col])
                                                                   : reinterpret_cast<const float *>(g.aux)[(size_t)row * g.ldaux + col];
-                        v *= gelu_erf_grad(a0);
+                        v *= g.aux_mode == 2 ? gelu_erf_grad(a0) : a0;
                     }
                     if (do_gelu) {
                         v = gelu_erf(v);
@@ -326,6 +330,9 @@ __device__ __forceinline__ void gemm_vec_epilogue(const GemmArgs &g, const f32x1
         if (g.aux_mode == 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(a4[e]);
+        } else if (g.aux_mode == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= a4[e];
         }
         if (do_gelu) {
 #pragma unroll
@@ -363,7 +370,7 @@ __device__ __forceinline__ void gemm_vec_epilogue(const GemmArgs &g, const f32x1
                     f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c8), v1 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c8 + 4);
                     float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
                     bf16_t *auxp = reinterpret_cast<bf16_t *>(g.aux) + (size_t)row * g.ldaux + col_base + c8;
-                    if (g.aux_mode == 2) {        // saved pre-activation: ONE 16-byte load per lane
+                    if (g.aux_mode == 2 || g.aux_mode == 4) {        // saved pre-activation / derivative: ONE 16-byte load per lane
                         const uint4 r4 = *reinterpret_cast<const uint4 *>(auxp);
                         a0[0] = __uint_as_float(r4.x << 16); a0[1] = __uint_as_float(r4.x & 0xFFFF0000u);
                         a0[2] = __uint_as_float(r4.y << 16); a0[3] = __uint_as_float(r4.y & 0xFFFF0000u);
@@ -372,6 +379,11 @@ __device__ __forceinline__ void gemm_vec_epilogue(const GemmArgs &g, const f32x1
                     } else if (g.aux_mode == 1) {  // keep the pre-activation: ONE 16-byte store per lane (was two 8-byte ones: the tail is store-issue bound)
                         uint4 p4;
                         p4.x = pack_bf16(v0[0], v0[1]); p4.y = pack_bf16(v0[2], v0[3]); p4.z = pack_bf16(v1[0], v1[1]); p4.w = pack_bf16(v1[2], v1[3]);
+                        *reinterpret_cast<uint4 *>(auxp) = p4;
+                    } else if (g.aux_mode == 3) {  // keep gelu'(pre-activation)
+                        uint4 p4;
+                        p4.x = pack_bf16(gelu_erf_grad(v0[0]), gelu_erf_grad(v0[1])); p4.y = pack_bf16(gelu_erf_grad(v0[2]), gelu_erf_grad(v0[3]));
+                        p4.z = pack_bf16(gelu_erf_grad(v1[0]), gelu_erf_grad(v1[1])); p4.w = pack_bf16(gelu_erf_grad(v1[2]), gelu_erf_grad(v1[3]));
                         *reinterpret_cast<uint4 *>(auxp) = p4;
                     }
                     finish(v0, row, col_base + c8, a0);
@@ -390,12 +402,14 @@ __device__ __forceinline__ void gemm_vec_epilogue(const GemmArgs &g, const f32x1
                     f32x4 v0 = *reinterpret_cast<const f32x4 *>(stg + r * EP + c4);
                     float a0[4] = {0.f, 0.f, 0.f, 0.f};
                     float *auxp = reinterpret_cast<float *>(g.aux) + (size_t)row * g.ldaux + col_base + c4;
-                    if (g.aux_mode == 2) {
+                    if (g.aux_mode == 2 || g.aux_mode == 4) {
                         const f32x4 r4 = *reinterpret_cast<const f32x4 *>(auxp);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) a0[e] = r4[e];
                     } else if (g.aux_mode == 1) {
                         *reinterpret_cast<f32x4 *>(auxp) = v0;
+                    } else if (g.aux_mode == 3) {
+                        *reinterpret_cast<f32x4 *>(auxp) = f32x4{gelu_erf_grad(v0[0]), gelu_erf_grad(v0[1]), gelu_erf_grad(v0[2]), gelu_erf_grad(v0[3])};
                     }
                     finish(v0, row, col_base + c4, a0);
                     *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)row * ldc_e + col_base + c4) = v0;
@@ -1268,13 +1282,13 @@ __device__ __forceinline__ void pp_swap2(uint32_t &x, uint32_t &y) {
 }
 // MODE (compile-time: one kernel instantiation per epilogue form - with every form in one body the kernel was > 100 KB of code, more than the
 // instruction cache, and a plain bf16 epilogue took ~10 us per tile walking around the other forms' blocks)
-enum { PP_OBF = 1, PP_GELU = 2, PP_AUX1 = 4, PP_AUX2 = 8, PP_RES = 16, PP_SCALE = 32, PP_DEFER = 64 };
+enum { PP_OBF = 1, PP_GELU = 2, PP_AUX1 = 4, PP_AUX2 = 8, PP_RES = 16, PP_SCALE = 32, PP_DEFER = 64, PP_AUX3 = 128, PP_AUX4 = 256 };
 template <int MODE>
 __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 (&acc)[8][4], int m0, int n0, int lane, float bv, void *dst = nullptr,
                                                  int ldd = 0) {
     const int lm = lane & 15, lq = lane >> 4;
     constexpr bool obf = MODE & PP_OBF, do_gelu = MODE & PP_GELU, has_res = MODE & PP_RES, has_scale = MODE & PP_SCALE;
-    constexpr int aux_mode = (MODE & PP_AUX1) ? 1 : ((MODE & PP_AUX2) ? 2 : 0);
+    constexpr int aux_mode = (MODE & PP_AUX1) ? 1 : ((MODE & PP_AUX2) ? 2 : ((MODE & PP_AUX3) ? 3 : ((MODE & PP_AUX4) ? 4 : 0)));
     const bool do_round = g.flags & ACAI_GEMM_ROUND_BF16;
     const bool pre_round = do_round && (do_gelu || aux_mode != 0 || has_res || !obf);
     constexpr int es = obf ? 2 : 4;
@@ -1328,7 +1342,7 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
             const int mb = P_INNER ? 2 * it_o + (sl >> 1) : 4 * (it_o & 1) + sl;
             const int row = m0 + mb * 16 + lm;
             const bool rowok = row < g.M;
-            if constexpr (aux_mode == 2) {
+            if constexpr (aux_mode == 2 || aux_mode == 4) {
                 if constexpr (obf) {
                     const bool swok = rowok && (sw_col + p * 32) < g.N;
                     prex[mb][P_INNER ? p : 0] = __builtin_amdgcn_raw_buffer_load_b128(rx, swok ? (uint32_t)(((size_t)row * g.ldaux + sw_col + p * 32) * 2) : OOB, 0, 0);
@@ -1360,7 +1374,7 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
             const uint32_t off_sw_c = swok ? (uint32_t)(((size_t)row * ldc + sw_col + p * 32) * 2) : OOB;
             const uint32_t off_sw_x = swok ? (uint32_t)(((size_t)row * g.ldaux + sw_col + p * 32) * 2) : OOB;
             float a0[2][4] = {};
-            if constexpr (aux_mode == 2) {
+            if constexpr (aux_mode == 2 || aux_mode == 4) {
                 if constexpr (obf) {
                     const u32x4_t L = prex[mb][P_INNER ? p : 0];
                     uint32_t x0 = L[0], x1 = L[1], y0 = L[2], y1 = L[3];
@@ -1396,10 +1410,23 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
                     v[t][2] = __uint_as_float(rp[t][1] << 16); v[t][3] = __uint_as_float(rp[t][1] & 0xFFFF0000u);
                 }
             }
-            if constexpr (aux_mode == 1) {   // keep the pre-activation
+            [[maybe_unused]] float dg[2][4];   // aux_mode 3: gelu'(pre-activation), formed with the GELU below from one Phi(-|a|)
+            if constexpr (aux_mode == 3) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float gv;
+                        gelu_erf_both(v[t][e], gv, dg[t][e]);
+                        v[t][e] = gv;
+                    }
+            }
+            if constexpr (aux_mode == 1 || aux_mode == 3) {   // keep the pre-activation (1) / its GELU derivative (3)
                 if constexpr (obf) {
                     uint32_t x0, x1, y0, y1;
-                    if (pre_round) {
+                    if constexpr (aux_mode == 3) {
+                        x0 = pack_bf16(dg[0][0], dg[0][1]); x1 = pack_bf16(dg[0][2], dg[0][3]); y0 = pack_bf16(dg[1][0], dg[1][1]); y1 = pack_bf16(dg[1][2], dg[1][3]);
+                    } else if (pre_round) {
                         x0 = rp[0][0]; x1 = rp[0][1]; y0 = rp[1][0]; y1 = rp[1][1];
                     } else {
                         x0 = pack_bf16(v[0][0], v[0][1]); x1 = pack_bf16(v[0][2], v[0][3]); y0 = pack_bf16(v[1][0], v[1][1]); y1 = pack_bf16(v[1][2], v[1][3]);
@@ -1412,7 +1439,8 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
                     for (int t = 0; t < 2; ++t) {
                         const int nb = 2 * p + t, col = n0 + nb * 16 + 4 * lq;
                         const uint32_t o = (rowok && colok[nb]) ? (uint32_t)(((size_t)row * g.ldaux + col) * 4) : OOB;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[t]), rx, o, 0, 0);
+                        if constexpr (aux_mode == 3) __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(dg[t][0]), __float_as_uint(dg[t][1]), __float_as_uint(dg[t][2]), __float_as_uint(dg[t][3])}, rx, o, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[t]), rx, o, 0, 0);
                     }
                 }
             }
@@ -1423,10 +1451,14 @@ __device__ __forceinline__ void gemm_pp_epilogue(const GemmArgs &g, const f32x4 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[t][e] *= gelu_erf_grad(a0[t][e]);
                 }
+                if constexpr (aux_mode == 4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[t][e] *= a0[t][e];
+                }
                 if constexpr (do_gelu) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[t][e] = gelu_erf(v[t][e]);
+                        if constexpr (aux_mode != 3) v[t][e] = gelu_erf(v[t][e]);   // (3: done above, together with the derivative)
                         if (do_round && !obf) v[t][e] = round_bf16(v[t][e]);   // (bf16 output: the pack below is that rounding)
                     }
                 }
@@ -1624,7 +1656,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
             default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         }
     };
-    constexpr int n_st = (MODE & PP_OBF) ? ((MODE & PP_AUX1) ? 32 : 16) : 32;   // store instructions per wave and tile (host: vec_epi only)
+    constexpr int n_st = (MODE & PP_OBF) ? ((MODE & (PP_AUX1 | PP_AUX3)) ? 32 : 16) : 32;   // store instructions per wave and tile (host: vec_epi only)
 
     // The bias of the tile in flight, one column per lane (lane L: bias[bn0 + wn*64 + L]); the epilogue distributes it with ds_bpermute and
     // issues no vector-memory load of its own.  A compiler-visible load anywhere in this loop is waited for with vmcnt(0) at its first use,
@@ -2149,10 +2181,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
 // epilogue form of a launch as gemm_nt_pp_kernel's MODE, and the forms it is instantiated for (the others keep variant 6)
 static inline int pp_mode(const GemmArgs &g) {
     return (g.out_dtype == ACAI_BF16 ? PP_OBF : 0) | ((g.flags & ACAI_GEMM_GELU) ? PP_GELU : 0) | (g.aux_mode == 1 ? PP_AUX1 : 0) | (g.aux_mode == 2 ? PP_AUX2 : 0) |
+           (g.aux_mode == 3 ? PP_AUX3 : 0) | (g.aux_mode == 4 ? PP_AUX4 : 0) |
            (g.residual ? PP_RES : 0) | (g.scale_cols > 0 ? PP_SCALE : 0);
 }
 static inline bool pp_mode_ok(int m) {
-    return m == PP_OBF || m == (PP_OBF | PP_SCALE) || m == (PP_OBF | PP_GELU | PP_AUX1) || m == (PP_OBF | PP_AUX2) || m == 0 || m == PP_RES;
+    return m == PP_OBF || m == (PP_OBF | PP_SCALE) || m == (PP_OBF | PP_GELU | PP_AUX1) || m == (PP_OBF | PP_AUX2) || m == 0 || m == PP_RES ||
+           m == (PP_OBF | PP_GELU | PP_AUX3) || m == (PP_OBF | PP_AUX4);
 }
 
 int g_gemm_variant = getenv("ACAI_GEMM_VARIANT") ? atoi(getenv("ACAI_GEMM_VARIANT")) : 0;
@@ -2315,6 +2349,8 @@ int launch(const GemmArgs &g, hipStream_t st) {
                         PP_CASE(PP_OBF | PP_SCALE);
                         PP_CASE(PP_OBF | PP_GELU | PP_AUX1);
                         PP_CASE(PP_OBF | PP_AUX2);
+                        PP_CASE(PP_OBF | PP_GELU | PP_AUX3);
+                        PP_CASE(PP_OBF | PP_AUX4);
                         PP_CASE(0);
                         PP_CASE(PP_RES);
 #undef PP_CASE
@@ -2358,9 +2394,9 @@ extern "C" int acai_gemm_nt_ex(const void *A, int lda, const void *W, int ldw, c
     ACAI_CHECK_ARG(lda >= K && ldw >= K && ldc >= N && (!residual || ldr >= N), "acai_gemm_nt: leading dimension smaller than row");
     ACAI_CHECK_ARG((in_dtype == ACAI_F32 || in_dtype == ACAI_BF16) && (out_dtype == ACAI_F32 || out_dtype == ACAI_BF16),
                    "acai_gemm_nt: bad dtype");
-    ACAI_CHECK_ARG(aux_mode >= 0 && aux_mode <= 2 && (aux_mode == 0 || (aux && ldaux >= N)), "acai_gemm_nt_ex: bad aux operand (mode %d)", aux_mode);
-    ACAI_CHECK_ARG(aux_mode != 1 || (flags & ACAI_GEMM_GELU), "acai_gemm_nt_ex: aux_mode 1 keeps the pre-activation of a GELU epilogue");
-    ACAI_CHECK_ARG(aux_mode != 2 || !(flags & ACAI_GEMM_GELU), "acai_gemm_nt_ex: aux_mode 2 (GELU derivative) excludes the GELU flag");
+    ACAI_CHECK_ARG(aux_mode >= 0 && aux_mode <= 4 && (aux_mode == 0 || (aux && ldaux >= N)), "acai_gemm_nt_ex: bad aux operand (mode %d)", aux_mode);
+    ACAI_CHECK_ARG((aux_mode != 1 && aux_mode != 3) || (flags & ACAI_GEMM_GELU), "acai_gemm_nt_ex: aux_mode 1 / 3 keep the pre-activation / its derivative of a GELU epilogue");
+    ACAI_CHECK_ARG((aux_mode != 2 && aux_mode != 4) || !(flags & ACAI_GEMM_GELU), "acai_gemm_nt_ex: aux_mode 2 / 4 (GELU derivative) exclude the GELU flag");
     ACAI_CHECK_ARG((flags & ~(ACAI_GEMM_GELU | ACAI_GEMM_ROUND_BF16)) == 0, "acai_gemm_nt: unknown flag bits 0x%x", flags);
     if (M == 0) return 0;
     GemmArgs g{};

@@ -80,10 +80,12 @@ def layernorm(x, w, b, eps, want_f32=True, want_bf16=False, out_f32=None):
 
 
 def gemm_nt(a, w, bias=None, residual=None, out_dtype=torch.float32, gelu=False, round_bf16=False, out=None, pre_act=None, gelu_grad_of=None,
-            col_scale=None):
+            col_scale=None, gelu_grad_out=None, times=None):
     """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias) (+ residual).  a, w share a dtype (fp32 or bf16); 2-D, row stride free.
     pre_act (with gelu): [M,N] tensor of out's dtype that receives the pre-activation; gelu_grad_of: [M,N] saved pre-activation whose GELU
-    derivative multiplies the (rounded) product; col_scale = (n, s): columns [0, n) of (a @ w^T + bias) are multiplied by s before rounding
+    derivative multiplies the (rounded) product; gelu_grad_out (with gelu): [M,N] tensor that receives gelu'(pre-activation) instead (the
+    forward epilogue holds Phi(-|a|) anyway) and times: [M,N] saved tensor that multiplies the (rounded) product - together the MLP's backward
+    epilogue is one multiply per element; col_scale = (n, s): columns [0, n) of (a @ w^T + bias) are multiplied by s before rounding
     (the in-projection hands q to the attention kernels as q * log2(e) / sqrt(dh), see attn_varlen(q_prescaled=True))."""
     _chk(a, "a"), _chk(w, "w")
     assert a.dim() == 2 and w.dim() == 2 and a.dtype == w.dtype and a.shape[1] == w.shape[1], (a.shape, w.shape, a.dtype, w.dtype)
@@ -97,13 +99,15 @@ def gemm_nt(a, w, bias=None, residual=None, out_dtype=torch.float32, gelu=False,
     if residual is not None:
         assert residual.dtype == torch.float32 and residual.shape == (M, N) and residual.stride(1) == 1
     flags = (GEMM_GELU if gelu else 0) | (GEMM_ROUND_BF16 if round_bf16 else 0)
-    aux = pre_act if pre_act is not None else gelu_grad_of
+    given = [(m, t) for m, t in ((1, pre_act), (2, gelu_grad_of), (3, gelu_grad_out), (4, times)) if t is not None]
+    assert len(given) <= 1, "one auxiliary operand per launch"
+    aux = given[0][1] if given else None
     if aux is not None or col_scale is not None:
         mode = 0
         if aux is not None:
-            assert (pre_act is None) != (gelu_grad_of is None) and aux.shape == (M, N) and aux.dtype == out.dtype and aux.stride(1) == 1
-            assert (pre_act is None) or gelu
-            mode = 1 if pre_act is not None else 2
+            mode = given[0][0]
+            assert aux.shape == (M, N) and aux.dtype == out.dtype and aux.stride(1) == 1
+            assert gelu == (mode in (1, 3))
         ncol, cs = col_scale if col_scale is not None else (0, 1.0)
         _lib.check(_lib.lib().acai_gemm_nt_ex(a.data_ptr(), _ld(a), w.data_ptr(), _ld(w), _p(bias), _p(residual),
                                               _ld(residual) if residual is not None else 0, out.data_ptr(), _ld(out),

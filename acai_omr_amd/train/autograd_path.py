@@ -255,8 +255,14 @@ class MlpFn(Function):
         bf = prec == "bf16"
         cdt = torch.bfloat16 if bf else torch.float32
         x = _compute_copy(x32, prec)
+        # `a` keeps gelu'(pre-activation), not the pre-activation: the forward epilogue holds Phi(-|a|) for the GELU anyway, and the backward
+        # epilogue of linear2's dX GEMM is then ONE multiply per element (it was VALU-bound on the derivative: tools/ablate_gelu_grad.py).
+        # ACAI_GELU_KEEP_PRE=1 restores the kept pre-activation (A/B aid; bitwise the round-3 arithmetic)
         a = torch.empty(x.shape[0], W1.shape[0], dtype=cdt, device=x.device)
-        h = ops.gemm_nt(x, wc.w(W1, prec), wc.b(b1, prec), out_dtype=cdt, gelu=True, round_bf16=bf, pre_act=a)
+        if _GELU_KEEP_PRE:
+            h = ops.gemm_nt(x, wc.w(W1, prec), wc.b(b1, prec), out_dtype=cdt, gelu=True, round_bf16=bf, pre_act=a)
+        else:
+            h = ops.gemm_nt(x, wc.w(W1, prec), wc.b(b1, prec), out_dtype=cdt, gelu=True, round_bf16=bf, gelu_grad_out=a)
         y = ops.gemm_nt(h, wc.w(W2, prec), wc.b(b2, prec), residual=x32, out_dtype=torch.float32, round_bf16=bf)
         ctx.save_for_backward(x, a, h, W1, W2, b1, b2)
         ctx.prec, ctx.wc = prec, wc
@@ -268,7 +274,10 @@ class MlpFn(Function):
         prec, wc, bf = ctx.prec, ctx.wc, ctx.prec == "bf16"
         dy = dy.contiguous()
         dyc, cs = _grad_copy_cs(dy, prec)
-        da = ops.gemm_nt(dyc, wc.wt(W2, prec), out_dtype=a.dtype, round_bf16=bf, gelu_grad_of=a)     # (dY . W2) o gelu'(a)
+        if _GELU_KEEP_PRE:
+            da = ops.gemm_nt(dyc, wc.wt(W2, prec), out_dtype=a.dtype, round_bf16=bf, gelu_grad_of=a)     # (dY . W2) o gelu'(a)
+        else:
+            da = ops.gemm_nt(dyc, wc.wt(W2, prec), out_dtype=a.dtype, round_bf16=bf, times=a)            # (dY . W2) o [gelu'(a), kept by the forward]
         dW2, db2 = _wbgrad(W2, b2, dyc, h, cs, ctx.needs_input_grad[3], ctx.needs_input_grad[4])
         dx = None
         if ctx.needs_input_grad[0]:   # branch gradient (rounded to the compute dtype as the unfused path does) + residual gradient, fp32
@@ -320,6 +329,7 @@ class SelfAttnBlockFn(Function):
 
 
 _FUSED_MLP = os.environ.get("ACAI_FUSED_MLP", "1") != "0"   # A/B aid
+_GELU_KEEP_PRE = os.environ.get("ACAI_GELU_KEEP_PRE", "0") == "1"   # A/B aid: MlpFn keeps the pre-activation (round 3) instead of its GELU derivative
 _QPRESCALE = os.environ.get("ACAI_QPRESCALE", "1") != "0"   # A/B aid: q leaves the in-projection already scaled for the attention kernels
 _LN_COLSUM = os.environ.get("ACAI_LN_COLSUM", "1") != "0"   # A/B aid: LayerNorm backward also forms the consuming Linear's bias gradient
 

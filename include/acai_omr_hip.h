@@ -47,7 +47,10 @@ int acai_gemm_nt(const void *A, int lda, const void *W, int ldw, const float *bi
 /* acai_gemm_nt with an auxiliary [M][N] operand of C's dtype (the MLP of nn.TransformerEncoderLayer / DecoderLayer in training:
  * linear1 -> GELU -> linear2, acai_omr/models/models.py:30-34,186-190,422-426 and their autograd):
  *   aux_mode 1 (with ACAI_GEMM_GELU): aux receives the pre-activation (bias added, bf16-rounded if asked), C its GELU - the forward keeps both;
- *   aux_mode 2: C = round(A.W^T) * gelu'(aux) - the dX GEMM of linear2 multiplies by the GELU derivative of the saved pre-activation.
+ *   aux_mode 2: C = round(A.W^T) * gelu'(aux) - the dX GEMM of linear2 multiplies by the GELU derivative of the saved pre-activation;
+ *   aux_mode 3 (with ACAI_GEMM_GELU): as 1, but aux receives gelu'(pre-activation) - the forward epilogue holds Phi(-|a|) for the GELU anyway;
+ *   aux_mode 4: C = round(A.W^T) * aux - with 3, the backward epilogue is one multiply per element (what the training steps use since round 4;
+ *               the derivative is rounded to C's dtype once more than in the 1 / 2 pair: 2^-9 relative in bf16, nothing in fp32).
  * scale_cols > 0: columns [0, scale_cols) of (A.W^T + bias) are multiplied by col_scale before rounding - the in-projection of
  * nn.MultiheadAttention hands q to the attention kernels as q * log2(e) / sqrt(dh) (acai_attn_varlen_fwd, q_prescaled). */
 int acai_gemm_nt_ex(const void *A, int lda, const void *W, int ldw, const float *bias, const float *residual, int ldr,

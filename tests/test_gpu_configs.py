@@ -178,6 +178,89 @@ def test_config3_teacher_forced_bf16_step_at_size_vs_oracle(dev):
         assert r < 2e-2 and c > 0.9999, (n, r, c)            # measured 3e-3 ... 5e-3, cosine 0.999996
 
 
+# ---- config 5: the single-rank arithmetic of its largest ragged shard shapes ------------------------------------------------------------
+def test_config5_shard_shapes_mae_bf16_step_vs_oracle(dev):
+    """BASELINE config 5 deals 768 x 3072 images (N = 9216 patches) to every rank; no other test ran a training BACKWARD beyond N = 4096.
+    Full WIDTHS of the MAE (768-wide d_h = 64 encoder on the 2304 / 256 kept tokens, 512-wide d_h = 32 decoder over all 9216 / 1024 tokens,
+    i.e. the two-blocks-per-wave backward over 9216 keys), a ragged pair 768 x 3072 + 256 x 1024, two layers per stack (the oracle's autograd
+    keeps every N x N probability tensor: 5.4 GB per decoder layer at N = 9216): loss and named gradients against autograd through the CPU
+    oracle's bf16 restatement, the bars of the config-2 test."""
+    import oracle.vitomr_oracle as O
+    from acai_omr_amd.config import MASK_RATIO, PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH
+    from acai_omr_amd.models.models import MAE, MAELoss
+    _threads()
+    torch.manual_seed(12)
+    mae = MAE(MASK_RATIO, PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH, encoder_kwargs=dict(num_layers=2), decoder_kwargs=dict(num_layers=2))
+    _perturb(mae)
+    g = torch.Generator().manual_seed(13)
+    imgs = [torch.rand(1, 768, 3072, generator=g), torch.rand(1, 256, 1024, generator=g)]
+    noise = [torch.rand(9216, generator=g), torch.rand(1024, generator=g)]
+    names = ("decoder_unembed.weight", "decoder.decoder_blocks.layers.0.self_attn.in_proj_weight", "decoder.decoder_blocks.layers.1.linear1.weight",
+             "encoder.encoder_blocks.layers.0.self_attn.in_proj_weight", "mask_token", "encoder.projection.weight")
+    sd = {k: v.detach().clone().requires_grad_(k in names) for k, v in mae.state_dict().items()}
+    pred_o, lm_o, tgt_o, lens = O.mae_forward([(im, im) for im in imgs], noise, sd, PATCH_SIZE, MASK_RATIO, 12, 16, prec="bf16")
+    loss_o = O.mae_loss(pred_o, lm_o, tgt_o)
+    loss_o.backward()
+    mae = mae.to(dev).train()
+    with autocast(device_type="cuda", dtype=torch.bfloat16):
+        pred, loss_mask, target, _ = mae.forward_packed([(im.to(dev), im.to(dev)) for im in imgs], noises=noise)
+    loss = MAELoss()(pred, loss_mask, target)
+    loss.backward()
+    assert torch.equal(loss_mask.cpu(), lm_o)
+    e_pred = md(pred, pred_o)
+    print(f"config5 shard shapes (MAE): loss {float(loss):.5f} oracle {float(loss_o):.5f}  pred max|d| {e_pred:.3e}")
+    assert abs(float(loss) - float(loss_o)) < 2e-3 * max(1.0, abs(float(loss_o)))
+    assert e_pred < 0.06 * max(1.0, float(pred_o.abs().max()))
+    params = dict(mae.named_parameters())
+    for n in names:
+        r, c = relerr(params[n].grad, sd[n].grad), cosine(params[n].grad, sd[n].grad)
+        print(f"  grad {n}: rel max err {r:.3e} cosine {c:.6f}")
+        assert r < 2e-2 and c > 0.9999, (n, r, c)
+
+
+def test_config5_shard_shapes_teacher_forced_bf16_step_vs_oracle(dev):
+    """The teacher-forced half of config 5 at the same ragged pair: forward_train(tf_prob = 1) under autocast(bf16) with the encoder's d_h = 64
+    self-attention over 9216 tokens (forward: the one-wave-per-SIMD kernel with its 128-query tail launch for the 1024-token image; backward:
+    9216 keys) and the decoder's cross attention 513 queries x 9216 / 1024 keys; full widths, two encoder and two decoder layers."""
+    import oracle.vitomr_oracle as O
+    from acai_omr_amd.config import MAX_LMX_SEQ_LEN, PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH
+    from acai_omr_amd.models.models import FineTuneOMREncoder, OMRCELoss, OMRDecoder, ScheduledSamplingViTOMR
+    _threads()
+    torch.manual_seed(14)
+    enc = FineTuneOMREncoder(PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH, 2, num_layers=2, transformer_dropout=0.0)
+    dec = OMRDecoder(MAX_LMX_SEQ_LEN, VOCAB, num_layers=2, transformer_dropout=0.0)
+    m = ScheduledSamplingViTOMR(enc, None, dec, transition_head_dropout=0.0)
+    _perturb(m, unembed_scale=3.0)
+    g = torch.Generator().manual_seed(15)
+    imgs = [torch.rand(1, 768, 3072, generator=g), torch.rand(1, 256, 1024, generator=g)]
+    T = 512
+    lmx = [torch.cat([torch.tensor([0]), torch.randint(3, 227, (T - 1,), generator=g), torch.tensor([2])]),
+           torch.cat([torch.tensor([0]), torch.randint(3, 227, (T - 200,), generator=g), torch.tensor([2])])]
+    names = ("decoder.unembed.weight", "decoder.decoder_blocks.layers.0.multihead_attn.in_proj_weight", "decoder.decoder_blocks.layers.1.linear2.weight",
+             "transition_head.0.weight", "encoder.fine_tune_blocks.layers.1.linear1.weight", "encoder.fine_tune_blocks.layers.0.self_attn.in_proj_weight")
+    sd = {k: v.detach().clone().requires_grad_(k in names) for k, v in m.state_dict().items()}
+    pred_o, tgt_o = O.teacher_forced_forward(list(zip(imgs, lmx)), sd, 12, 16, PATCH_SIZE, "bf16")
+    loss_o = O.ce_loss(pred_o, tgt_o, 1)
+    loss_o.backward()
+    m = m.to(dev).train()
+    batch = [(im.to(dev), sq.to(dev)) for im, sq in zip(imgs, lmx)]
+    with autocast(device_type="cuda", dtype=torch.bfloat16):
+        pred, tgt = m.forward_train(batch, 1.0, 0.5, False)
+        loss = OMRCELoss(m.decoder.pad_idx)(pred, tgt)
+    loss.backward()
+    assert torch.equal(tgt.cpu(), tgt_o)
+    valid = tgt_o != 1
+    e_pred = md(pred.float().cpu()[valid], pred_o.detach()[valid])
+    print(f"config5 shard shapes (TF): loss {float(loss):.5f} oracle {float(loss_o):.5f}  logits max|d| {e_pred:.3e}")
+    assert abs(float(loss) - float(loss_o)) < 2e-3 * max(1.0, abs(float(loss_o)))
+    assert e_pred < 0.05 * max(1.0, float(pred_o.abs().max()))
+    params = dict(m.named_parameters())
+    for n in names:
+        r, c = relerr(params[n].grad, sd[n].grad), cosine(params[n].grad, sd[n].grad)
+        print(f"  grad {n}: rel max err {r:.3e} cosine {c:.6f}")
+        assert r < 2e-2 and c > 0.9999, (n, r, c)
+
+
 @pytest.mark.parametrize("name", ["tf_small", "tf_dh64"])
 def test_config3_teacher_forced_bf16_golden_sizes_vs_oracle(dev, name):
     """The same step on the golden fixtures' weights under autocast(bf16): logits, loss and every gradient the fp32 golden test checks."""

@@ -221,6 +221,8 @@ def test_attn_varlen_two_block_forward_zero_reference_restart(dev, shift):
     (1, [40, 129, 192], [40, 65, 191]),       # one ragged tile; two tiles with one key in the second; three tiles
     (2, [300], [128]),                        # two full tiles: prologue + one steady tile + drain, nothing masked
     (1, [256], [1]),                          # a single key
+    (2, [288, 289, 20], [700, 64, 1]),        # tails of exactly 32 rows (tail kernel: keys split over 8 waves, 11 tiles), of 33 (wide kernel) and a 20-row sequence
+    (1, [513] * 3, [1100] * 3),               # equal lengths: the host launches the tail kernel because 513 % 256 = 1
 ])
 def test_attn_fwd64_pipelined(dev, H, lens_q, lens_k):
     """attn_fwd64.hip (bf16, d_h = 64, q prescaled, no mask): the software-pipelined forward against the fp64 softmax, every tile-count class
@@ -397,6 +399,19 @@ def test_gemm_nt_gelu_aux_modes(dev, dtype, shape):
         assert bool((d <= 2.0 ** -7 * ref.float().abs() + 1e-6).all()) and float((d > 0).float().mean()) < 0.01, (float(d.max()), float((d > 0).float().mean()))
     else:
         assert torch.allclose(fused, ref, rtol=1e-5, atol=1e-6)   # fp32 contraction differences between the two kernels
+    # round 4 (what MlpFn uses): aux_mode 3 keeps gelu'(pre-activation) next to the GELU, aux_mode 4 multiplies the product by the kept tensor
+    dg = torch.empty(M, N, dtype=dt, device=dev)
+    h3 = ops.gemm_nt(a, w, b, out_dtype=dt, gelu=True, round_bf16=rnd, gelu_grad_out=dg)
+    assert torch.equal(h3, h)                                                    # the GELU itself is unchanged by what is kept beside it
+    dg_ref = ops.gelu_bwd(pre_ref, torch.ones(M, N, dtype=dt, device=dev))       # gelu'(pre) * 1 through the stand-alone kernel
+    dd = (dg.float() - dg_ref.float()).abs()
+    assert float(dd.max()) <= (2.0 ** -7 if dtype == "bf16" else 2e-6), float(dd.max())
+    prod = ops.gemm_nt(a, w, out_dtype=dt, round_bf16=rnd, times=saved)
+    ref4 = (ops.gemm_nt(a, w, out_dtype=dt, round_bf16=rnd).float() * saved.float()).to(dt)
+    if dtype == "bf16":
+        assert torch.equal(prod, ref4)      # one multiply of two bf16 values, rounded once: exact in both
+    else:
+        assert torch.allclose(prod, ref4, rtol=1e-6, atol=1e-7)
 
 
 @pytest.mark.gpu
@@ -486,6 +501,10 @@ def test_gemm_nt_pingpong_epilogues(dev, K, shape):
             out["gelu_bf16"] = ops.gemm_nt(a, w, b, out_dtype=bf, gelu=True, round_bf16=True, pre_act=pre)
             out["pre_bf16"] = pre
             out["dgelu_bf16"] = ops.gemm_nt(a, w, out_dtype=bf, round_bf16=True, gelu_grad_of=saved)
+            dgo = torch.empty(M, N, dtype=bf, device=dev)      # round 4: the forward keeps gelu'(pre-activation), the backward multiplies by it
+            out["gelu3_bf16"] = ops.gemm_nt(a, w, b, out_dtype=bf, gelu=True, round_bf16=True, gelu_grad_out=dgo)
+            out["dgelu_kept_bf16"] = dgo
+            out["times_bf16"] = ops.gemm_nt(a, w, out_dtype=bf, round_bf16=True, times=saved)
             out["scale_bf16"] = ops.gemm_nt(a, w, b, out_dtype=bf, round_bf16=True, col_scale=(N // 3 // 4 * 4, ops.QSCALE(64)))
             view = wide[:, 8:8 + N]
             ops.gemm_nt(a, w, b, out=view, round_bf16=True)
