@@ -338,23 +338,27 @@ __global__ __launch_bounds__(512) void attn_fwd64_tail_kernel(AttnArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
     float m_run = -1.0e30f, l_run = 0.f;   // running maximum of the lane's query (log2 domain) and this lane-half's partial row sum
-    for (int t = wave; t < nkt; t += 8) {
+    u32x4 rk[8], rv[8];
+    auto load_tile = [&](int t) {   // one wave stages both 8 KB tiles: chunk c = lane + 64 i -> row c / 8, 16-byte chunk c % 8 (tiles past the end: zeros)
         const int rows = lk - t * KT;
-        const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(K + (size_t)t * KT * a.ldk), 0, rows * a.ldk * 2, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(V + (size_t)t * KT * a.ldv), 0, rows * a.ldv * 2, 0x00020000);
-        u32x4 rk[8], rv[8];
+        const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(K + (size_t)t * KT * a.ldk), 0, rows > 0 ? rows * a.ldk * 2 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(V + (size_t)t * KT * a.ldv), 0, rows > 0 ? rows * a.ldv * 2 : 0, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {   // one wave stages both 8 KB tiles: chunk c = lane + 64 i -> row c / 8, 16-byte chunk c % 8
+        for (int i = 0; i < 8; ++i) {
             const int c = lane + 64 * i, row = c >> 3, cc = c & 7;
             rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rK, (uint32_t)(row * a.ldk * 2 + cc * 16), 0, 0);
             rv[i] = __builtin_amdgcn_raw_buffer_load_b128(rV, (uint32_t)(row * a.ldv * 2 + cc * 16), 0, 0);
         }
+    };
+    load_tile(wave);
+    for (int t = wave; t < nkt; t += 8) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c = lane + 64 * i, off = TL::off(c >> 3, c & 7);
             *reinterpret_cast<u32x4 *>(ldsK + off) = rk[i];
             *reinterpret_cast<u32x4 *>(ldsV + off) = rv[i];
         }
+        load_tile(t + 8);   // the wave's next tile travels while this one is computed on (a lone load -> compute chain took ~6 us per tile)
         // (wave-private image: the wave's own LDS operations complete in order - no barrier between its stores and its reads, nor between
         // this tile's reads and the next tile's stores)
         f32x16 sacc[2];
@@ -467,7 +471,10 @@ int acai_attn_fwd64_launch(const AttnArgs &a, int B, int max_q, hipStream_t st) 
         const int rem = max_q % 256;
         const bool need_tail = !all_equal || (rem > 0 && rem <= 32);
         w.tail = need_tail ? 32 : 0;
-        if (!(all_equal && max_q <= 32)) acai_attn_fwd64w_launch(w, B, max_q, st);
+        // (equal lengths: the wide grid covers the full blocks only - workgroups that exit at once still wait for a whole free CU each, one
+        // per (sequence, head): 192 against 147 us on the decoder's 513-query cross attention)
+        const int wide_q = (all_equal && need_tail) ? max_q - rem : max_q;
+        if (wide_q > 0) acai_attn_fwd64w_launch(w, B, wide_q, st);
         if (need_tail) hipLaunchKernelGGL(attn_fwd64_tail_kernel, dim3(1, a.H, B), dim3(512), 0, st, w);
         return 0;
     }
