@@ -24,7 +24,9 @@ def fwd(name, M, N, K, count, resid=False, gelu=False, out32=False, dgelu=False,
     out = torch.empty(M, N, device=dev, dtype=torch.float32 if (resid or out32) else bf)
     pre = torch.empty(M, N, device=dev, dtype=bf) if gelu else None
     saved = torch.randn(M, N, device=dev).to(bf) if dgelu else None      # the kept pre-activation whose GELU derivative multiplies the product
-    s = t(lambda: ops.gemm_nt(a, w, None if dgelu else b, residual=r, out=out, gelu=gelu, round_bf16=True, pre_act=pre, gelu_grad_of=saved,
+    keep_pre = os.environ.get("ACAI_GELU_KEEP_PRE") == "1"   # round 3's form: the forward keeps the pre-activation, the backward evaluates gelu' (default: the forward keeps gelu', the backward multiplies)
+    s = t(lambda: ops.gemm_nt(a, w, None if dgelu else b, residual=r, out=out, gelu=gelu, round_bf16=True, pre_act=pre if keep_pre else None,
+                              gelu_grad_out=None if keep_pre else pre, gelu_grad_of=saved if keep_pre else None, times=None if keep_pre else saved,
                               col_scale=(N // 3, 0.18) if scale else None))
     rows.append((name, M, N, K, count, s))
 

@@ -19,7 +19,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             n = r["Kernel_Name"]
             if not pat.search(n) or r["Counter_Name"] != ctr:
                 continue
-            short = re.sub(r"\(anonymous namespace\)::", "", n.split("(")[0]).replace("unsigned short", "bf16").replace("void ", "")
+            short = re.sub(r"\(anonymous namespace\)::", "", n).split("(")[0].replace("unsigned short", "bf16").replace("void ", "")
             key = (short[:90], int(r["Grid_Size"]))
             acc[key][ctr].append(float(r["Counter_Value"]))
             acc[key]["ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))

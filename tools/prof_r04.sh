@@ -7,9 +7,11 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dec
 for L in mae tf ragged; do
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$L -o $L -- python3 $R/tools/prof_leg.py $L > $O/$L.log 2>&1 || echo $L failed
 done
+export ACAI_BENCH_NO_GRAPH=1   # counter collection over the 8-step decode graph segfaults inside rocprofv3: the PMC passes enqueue the same launches one by one
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C -d $O/pmc_$C -o r --output-format csv -- python3 $R/bench.py --steps 16 --warmup 4 --no-cpu-baseline --legs "" > $O/log_$C.txt 2>&1 || echo "$C failed"
 done
+unset ACAI_BENCH_NO_GRAPH
 python3 $R/tools/pmc_summarise.py $O r04 > $O/pmc_summary.log 2>&1
 # LayerNorm kernels of the MAE step: fetched / written bytes against the minimum (verdict r3 item 6)
 mkdir -p $O/ln
