@@ -747,7 +747,7 @@ def main():
         # HBM traffic of the same kernel: NOT measured in this run - the value of the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
         # separate runs, gfx950 correction applied); only quoted when they were taken on this workload shape
         traffic, traffic_src = None, None
-        for name in ("r03_pmc_cross_attn.json", "r02_pmc_cross_attn.json", "r01_pmc_cross_attn.json"):
+        for name in ("r04_pmc_cross_attn.json", "r02_pmc_cross_attn.json", "r01_pmc_cross_attn.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc) and a.batch == 8 and S == 4096:
                 traffic, traffic_src = json.load(open(pmc))["hbm_bytes_per_launch"], "profiles/" + name + " (static: rocprofv3 --pmc passes of this workload, not collected in this run)"
