@@ -10,6 +10,11 @@ is the command-line form.
 2. attn_fwd64w_kernel (attn_fwd64w.hip): the tile barrier waits `lgkmcnt(4)` instead of draining the LDS queue - it relies on EXACTLY the four
    fragment reloads of the last two MFMA gaps being issued behind the staged tiles' ds_write_b128.  More LDS operations there and the counted
    wait no longer covers the stores.
+3. attn_fwd64w.hip / attn_bwd64w.hip: MFMAs issued from inline asm (accumulator-register C / D).  A VALU write of a register needs two wait
+   states before an MFMA reads it; hipcc pads its own MFMAs and knows nothing about an asm one.  Round 4 hit this for real: the compiler's
+   v_accvgpr_mov / v_accvgpr_write copies that assemble an operand tuple sat directly in front of the asm statement and a few 32 x 32 blocks of
+   the d_h = 64 gradients came out wrong (tools/dbg_bwd64w.py).  Every asm MFMA: no v_* instruction may write one of its source registers in
+   the two wait states in front of it (an `s_nop N` counts N + 1, any other instruction 1).
 """
 import re
 
@@ -93,4 +98,64 @@ def check_fwd64w_barrier(src, kernels=r"_ZN12_GLOBAL__N_118attn_fwd64w_kernel", 
                 problems.append(f"{name}: +{i}: {lds_after} LDS operations behind the tile stores, the barrier waits lgkmcnt({allowed})")
     if n == 0:
         problems.append("attn_fwd64w_kernel: no counted tile barrier found (kernel renamed or restructured? update acai_omr_amd/_asmcheck.py)")
+    return problems, n
+
+
+_AREG = re.compile(r"\ba(\d+)\b")
+_ARANGE = re.compile(r"a\[(\d+):(\d+)\]")
+
+
+def _regs_va(text):
+    """{('v', n), ('a', n)} named in an operand string."""
+    used = {("v", r) for r in _regs_of(text)}
+    for a, b in _ARANGE.findall(text):
+        used |= {("a", r) for r in range(int(a), int(b) + 1)}
+    for a in _AREG.findall(text):
+        used.add(("a", int(a)))
+    return used
+
+
+def check_asm_mfma_operands(src, kernels=r"_ZN12_GLOBAL__N_1\d+attn_(?:fwd64w|bwd64w_dq|bwd64w_dkv)_kernel", need=2):
+    """Every `v_mfma*` between ;;#ASMSTART / ;;#ASMEND: the VALU instructions within `need` wait states in front of it (s_nop inside the asm
+    statement included) must not write its A / B / C source registers."""
+    problems, n = [], 0
+    for name, body in _functions(src, kernels):
+        in_asm = False
+        for i, ln in enumerate(body):
+            t = ln.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if not (in_asm and t.startswith("v_mfma")):
+                continue
+            n += 1
+            ops = t.split(None, 1)[1].split(",")
+            srcs = set()
+            for o in ops[1:]:
+                srcs |= _regs_va(o)
+            waited = 0
+            for j in range(i - 1, -1, -1):
+                u = body[j].strip()
+                if not u or u.startswith(";") or u.startswith(".") or u.endswith(":"):
+                    continue
+                mn = re.match(r"s_nop\s+(\d+)", u)
+                if mn:
+                    waited += int(mn.group(1)) + 1
+                elif u.startswith("v_mfma"):
+                    waited += 2   # (an accumulate chain on the same C / D registers is legal back to back; an MFMA holds the issue port >= 2 slots)
+                elif u.startswith("v_"):
+                    dst = u.split(None, 1)[1].split(",")[0] if " " in u else ""
+                    if not u.startswith("v_cmp") and _regs_va(dst) & srcs:
+                        problems.append(f"{name}: +{i}: `{t}` reads a register written {waited} wait states earlier by `{u}` (needs {need})")
+                        break
+                    waited += 1
+                else:
+                    waited += 1
+                if waited >= need:
+                    break
+    if n == 0:
+        problems.append("no inline-asm MFMA found (kernels renamed? update acai_omr_amd/_asmcheck.py)")
     return problems, n

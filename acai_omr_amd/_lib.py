@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("ACAI_OMR_LIB") or os.path.join(CSRC, "libacai_omr_hip.so")   # (override: A/B builds of the same sources, tools/ab_*.sh)
-SOURCES = ["gemm.hip", "elementwise.hip", "attn_varlen.hip", "attn_fwd64.hip", "attn_fwd64w.hip", "attn_bwd.hip", "train.hip", "decode.hip", "resize.hip"]
+SOURCES = ["gemm.hip", "elementwise.hip", "attn_varlen.hip", "attn_fwd64.hip", "attn_fwd64w.hip", "attn_bwd.hip", "attn_bwd64w.hip", "train.hip", "decode.hip", "resize.hip"]
 
 ACAI_F32, ACAI_BF16 = 0, 1
 GEMM_GELU, GEMM_ROUND_BF16 = 1, 2
@@ -117,7 +117,8 @@ def build(force=False, verbose=False):
     # more issue time than the two v_mul_f32 it replaces (PMC: +24 % VALU instructions without it, -9 % wave cycles).
     per_file = {"attn_varlen.hip": ["-fno-slp-vectorize"], "attn_fwd64.hip": ["-fno-slp-vectorize"],
                 # (one wave per SIMD: the score MFMAs must write VGPRs, the output accumulators are asm-owned AGPRs - see the file header)
-                "attn_fwd64w.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"], "attn_bwd.hip": ["-fno-slp-vectorize"]}
+                "attn_fwd64w.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"], "attn_bwd.hip": ["-fno-slp-vectorize"],
+                "attn_bwd64w.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]}
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
 
@@ -126,7 +127,8 @@ def build(force=False, verbose=False):
 
     # Sources whose correctness rests on something the compiler does not model (asm loads it cannot see, a counted LDS wait): their generated
     # assembly is checked on every rebuild and a hit FAILS the build (acai_omr_amd/_asmcheck.py; ADVICE r3: the check used to be a manual tool).
-    asm_checks = {"gemm.hip": "check_untracked_loads", "attn_fwd64w.hip": "check_fwd64w_barrier"}
+    asm_checks = {"gemm.hip": ["check_untracked_loads"], "attn_fwd64w.hip": ["check_fwd64w_barrier", "check_asm_mfma_operands"],
+                  "attn_bwd64w.hip": ["check_asm_mfma_operands"]}
     jobs, to_check = [], []
     for src in srcs:
         base = os.path.basename(src)
@@ -148,9 +150,12 @@ def build(force=False, verbose=False):
                     raise RuntimeError(f"hipcc failed: {' '.join(r.args)}\n{r.stdout}\n{r.stderr}")
     from . import _asmcheck
     for base, asm in to_check:
-        problems, n = getattr(_asmcheck, asm_checks[base])(open(asm).read())
-        if verbose:
-            print(f"asm check {base}: {n} sites, {len(problems)} problems")
+        problems = []
+        for chk in asm_checks[base]:
+            pr, n = getattr(_asmcheck, chk)(open(asm).read())
+            problems += pr
+            if verbose:
+                print(f"asm check {base} ({chk}): {n} sites, {len(pr)} problems")
         if problems:
             os.remove(asm)   # (so that the next build checks again instead of trusting a stale pass)
             raise RuntimeError(f"generated code of {base} violates an assumption the kernel relies on:\n" + "\n".join(problems))

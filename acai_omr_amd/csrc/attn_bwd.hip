@@ -11,7 +11,7 @@
 //                    S = Q K^T,  P,  dV^T += dO^T P,  dP = dO V^T,  dS = P o (dP - delta),  dK^T += Q^T dS
 // delta[q] = sum_d dO[q,d] O[q,d] is formed in the prologue of attn_bwd_dq (which runs first) and published for attn_bwd_dkv.  S and P are recomputed in both kernels (7 products instead
 // of 5) - the price of having no cross-workgroup reduction.  fp32: v_mfma_f32_32x32x2_f32, bf16: v_mfma_f32_32x32x16_bf16.
-#include "common.h"
+#include "attn_bwd_args.h"
 #include <type_traits>
 #ifndef ACAI_DKV_STRAIGHT
 #define ACAI_DKV_STRAIGHT 0
@@ -24,17 +24,6 @@ namespace {
 
 constexpr int TT = 64;   // streamed-side rows per tile
 constexpr int OB = 128;  // lane-owned rows per workgroup
-
-struct BwdArgs {
-    const void *q, *k, *v, *o, *dout;
-    void *dq, *dk, *dv;
-    const float *lse, *delta;  // [H][total_q]
-    const int32_t *cu_q, *cu_k;
-    int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, H, dh, causal, total_q;
-    float scale_log2e, scale;
-    uint32_t drop_thr, drop_seed;  // the forward's attention-probability dropout, regenerated element-wise
-    float drop_scale;
-};
 
 template <typename T, bool FAST>
 __device__ __forceinline__ uint4 ld16(const T *base, int ld, int row, int rows, int d0, int dh) {
@@ -202,7 +191,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     const int b = blockIdx.z, h = blockIdx.y;
     const int q_start = a.cu_q[b], lq = a.cu_q[b + 1] - q_start;
     const int k_start = a.cu_k[b], lk = a.cu_k[b + 1] - k_start;
-    const int q0 = blockIdx.x * OB;
+    const int q0 = ((a.tail256 & 1) ? (lq / 256) * 256 : 0) + blockIdx.x * OB;   // tail256 bit 0: only the rows past the last full 256-query block (attn_bwd64w.hip has the full ones)
     if (q0 >= lq) return;
     const int dh = a.dh;
     const T *Q = reinterpret_cast<const T *>(a.q) + (size_t)q_start * a.ldq + h * dh;
@@ -399,7 +388,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) 
     const int b = blockIdx.z, h = blockIdx.y;
     const int q_start = a.cu_q[b], lq = a.cu_q[b + 1] - q_start;
     const int k_start = a.cu_k[b], lk = a.cu_k[b + 1] - k_start;
-    const int k0 = blockIdx.x * OB;
+    const int k0 = ((a.tail256 & 2) ? (lk / 256) * 256 : 0) + blockIdx.x * OB;   // tail256 bit 1: only the keys past the last full 256-key block
     if (k0 >= lk) return;
     const int dh = a.dh;
     const T *Q = reinterpret_cast<const T *>(a.q) + (size_t)q_start * a.ldq + h * dh;
@@ -955,6 +944,38 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, bool pre, hipStrea
             if (nq_env == 2 && !a.causal && max_q >= 512 && max_k >= 512) {
                 hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(cdiv(max_q, 2 * OB), a.H, B), dim3(256), lds_dq, st, a);
                 hipLaunchKernelGGL(attn_bwd_dkv2_kernel, dim3(cdiv(max_k, 2 * OB), a.H, B), dim3(256), lds_dkv, st, a);
+                return;
+            }
+        }
+        if constexpr (sizeof(T) == 2 && DHP == 64 && F && !D && P) {
+            // the training steps' d_h = 64 form: one wave per SIMD, two lane-owned blocks per wave (attn_bwd64w.hip) over every sequence's full
+            // 256-row blocks; the rows past them (none for the encoder's 256-multiples, one for the decoder's 513 tokens) stay with the
+            // one-block kernels below, offset by tail256.  ACAI_ATTN64_BWD_WIDE: 0 off, 1 (default) dQ only, 2 dK/dV only, 3 both.
+            // Measured (tools/bench_cross_train_attn.py, 16 x 16 heads, same box): the wide dQ form is 1-5 % faster than the one-block kernel
+            // (encoder 4096 x 4096: 1533 against 1561 us; decoder cross 512 x 4096: 184 against 210 us), the wide dK/dV form is SLOWER
+            // (2894 against 2142 us: its 16 more live fragment registers spill to scratch, and a scratch reload's vmcnt(0) also waits for the
+            // staged tile in flight) - both are kept bit-identical to the one-block kernels and tested, only dQ is on.  Why neither gains
+            // what the forward's rebuild did: every d_h = 64 attention kernel already executes 1.03-1.10 PFLOP/s of MFMA work, the rate this
+            // chip sustains at its loaded clock with operands from LDS (tools/experiments/mfma_shape.hip: 1.25 PF for a bare loop that
+            // re-reads its operands from LDS, 1.82 PF from registers) - see DESIGN.md section 9.
+            static const int wide_env = getenv("ACAI_ATTN64_BWD_WIDE") ? atoi(getenv("ACAI_ATTN64_BWD_WIDE")) : 1;
+            if (wide_env && !a.causal && a.dh == 64) {
+                const bool wq = (wide_env & 1) && max_q >= 256, wk = (wide_env & 2) && max_k >= 256;
+                // when every sequence is max_q long (B * max_q rows in all) the host knows whether a tail exists; keys: only for self-attention
+                const bool eq_q = (long long)B * max_q == (long long)a.total_q, eq_k = eq_q && a.cu_k == a.cu_q && max_k == max_q;
+                BwdArgs t = a;
+                if (wq) acai_attn_bwd64w_dq_launch(a, B, max_q, st);
+                if (!wq || !eq_q || max_q % 256) {
+                    t.tail256 = wq ? 1 : 0;
+                    const int rows = wq ? (eq_q ? max_q % 256 : 255) : max_q;
+                    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DHP, F, D, P>), dim3(cdiv(rows, OB), a.H, B), dim3(256), lds_dq, st, t);
+                }
+                if (wk) acai_attn_bwd64w_dkv_launch(a, B, max_k, st);
+                if (!wk || !eq_k || max_k % 256) {
+                    t.tail256 = wk ? 2 : 0;
+                    const int rows = wk ? (eq_k ? max_k % 256 : 255) : max_k;
+                    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DHP, F, D, P>), dim3(cdiv(rows, OB), a.H, B), dim3(256), lds_dkv, st, t);
+                }
                 return;
             }
         }

@@ -1,0 +1,22 @@
+// Argument block of the varlen attention backward kernels (attn_bwd.hip: every dtype / head size / mask / dropout; attn_bwd64w.hip: the
+// one-wave-per-SIMD bf16 d_h = 64 form of the training steps).
+#pragma once
+#include "common.h"
+
+struct BwdArgs {
+    const void *q, *k, *v, *o, *dout;
+    void *dq, *dk, *dv;
+    const float *lse, *delta;  // [H][total_q]
+    const int32_t *cu_q, *cu_k;
+    int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, H, dh, causal, total_q;
+    float scale_log2e, scale;
+    uint32_t drop_thr, drop_seed;  // the forward's attention-probability dropout, regenerated element-wise
+    float drop_scale;
+    int tail256;   // attn_bwd.hip one-block kernels: > 0 = cover only the rows past each sequence's last full 256-row block (the full blocks belong to attn_bwd64w.hip)
+    int nblk;      // attn_bwd64w.hip: 256-row blocks per (sequence, head) of its one-dimensional, XCD-swizzled grid
+};
+
+// bf16, d_h = 64 exactly, q prescaled, no dropout, no causal mask, 16-byte aligned operands: the full 256-query blocks of dQ (which also
+// publishes -delta for every row of those blocks) and the full 256-key blocks of dK / dV (attn_bwd64w.hip)
+void acai_attn_bwd64w_dq_launch(const BwdArgs &a, int B, int max_q, hipStream_t st);
+void acai_attn_bwd64w_dkv_launch(const BwdArgs &a, int B, int max_k, hipStream_t st);

@@ -199,3 +199,18 @@ def test_asm_checks_flag_what_they_are_for():
     p, n = _asmcheck.check_fwd64w_barrier(bad)
     assert n == 1 and len(p) == 1 and "5 LDS operations" in p[0]
     assert _asmcheck.check_fwd64w_barrier("nothing here\n")[0]      # the kernel vanished: that is a finding too
+    # (3) an inline-asm MFMA whose source register a VALU instruction wrote less than two wait states earlier (round 4: the compiler's tuple copies
+    # in front of attn_bwd64w's asm MFMAs gave wrong gradients); an s_nop inside the asm statement, or two other instructions between, clear it;
+    # an accumulate chain of MFMAs on the same C / D registers is legal back to back
+    bhead = "_ZN12_GLOBAL__N_121attn_bwd64w_dq_kernelE7BwdArgs:\n"
+    mf = "\tv_mfma_f32_32x32x16_bf16 a[32:47], a[72:75], v[92:95], a[32:47]\n"
+    hazard = bhead + "\tv_accvgpr_mov_b32 a75, a3\n\t;;#ASMSTART\n" + mf + "\t;;#ASMEND\n\ts_endpgm\n"
+    padded = bhead + "\tv_accvgpr_mov_b32 a75, a3\n\t;;#ASMSTART\n\ts_nop 1\n" + mf + "\t;;#ASMEND\n\ts_endpgm\n"
+    spaced = bhead + "\tv_cvt_pk_bf16_f32 v93, v1, v2\n\tv_exp_f32_e32 v7, v8\n\tds_read_b128 v[20:23], v101\n\t;;#ASMSTART\n" + mf + "\t;;#ASMEND\n\ts_endpgm\n"
+    chain = bhead + "\t;;#ASMSTART\n" + mf + "\t;;#ASMEND\n\t;;#ASMSTART\n" + mf + "\t;;#ASMEND\n\ts_endpgm\n"
+    p, n = _asmcheck.check_asm_mfma_operands(hazard)
+    assert n == 1 and len(p) == 1 and "v_accvgpr_mov_b32 a75, a3" in p[0]
+    assert _asmcheck.check_asm_mfma_operands(padded) == ([], 1)
+    assert _asmcheck.check_asm_mfma_operands(spaced) == ([], 1)
+    assert _asmcheck.check_asm_mfma_operands(chain) == ([], 2)
+    assert _asmcheck.check_asm_mfma_operands("nothing here\n")[0]

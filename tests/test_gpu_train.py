@@ -58,6 +58,13 @@ def test_gemm_transposed_variants(dev, M, N, K, dtype):
     (2, 32, [513, 700], None, False),
     (2, 32, [600, 513], [1000, 577], False),
     (1, 24, [1025], [512], False),
+    # d_h = 64, bf16 prescaled, no mask, >= 256 rows: the one-wave-per-SIMD kernels over the full 256-row blocks + the one-block kernels over the
+    # rows past them (a one-row tail as in the decoder's 513 tokens, sequences shorter than a block, a ragged last key tile, cross lengths)
+    (2, 64, [513, 700], None, False),
+    (2, 64, [600, 256, 40], [1000, 577, 300], False),
+    (1, 64, [1025], [512], False),
+    (1, 64, [512], [330], False),
+    (3, 64, [768], [129], False),
 ])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("prescaled", [False, True])
@@ -106,6 +113,51 @@ def test_attn_backward(dev, H, dh, lens_q, lens_k, causal, dtype, prescaled):
     for name, got, ref in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
         err = (got.cpu().double() - ref).abs().max() / max(1.0, float(ref.abs().max()))
         assert err < tol, (name, float(err))
+
+
+_BWD64W_SNIPPET = r"""
+import sys, torch
+from acai_omr_amd import engine, ops
+dev, bf, dh, H = "cuda", torch.bfloat16, 64, 2
+lens_q, lens_k = [600, 300, 256], [1000, 577, 256]
+E = H * dh
+g = torch.Generator().manual_seed(11)
+q = (torch.randn(sum(lens_q), E, generator=g) * ops.QSCALE(dh)).to(dev).to(bf)
+k = torch.randn(sum(lens_k), E, generator=g).to(dev).to(bf)
+v = torch.randn(sum(lens_k), E, generator=g).to(dev).to(bf)
+do = torch.randn(sum(lens_q), E, generator=g).to(dev).to(bf)
+cu_q, cu_k = engine.cu_from_lens(lens_q, dev), engine.cu_from_lens(lens_k, dev)
+lse = torch.empty(H * sum(lens_q), device=dev)
+o = ops.attn_varlen(q, k, v, cu_q, cu_k, H, dh, max(lens_q), lse=lse, q_prescaled=True)
+dq, dk, dv = torch.full_like(q, 7.0), torch.full_like(k, 7.0), torch.full_like(v, 7.0)
+ops.attn_varlen_bwd(q, k, v, o, do, lse, cu_q, cu_k, H, dh, max(lens_q), max(lens_k), False, dq, dk, dv, q_prescaled=True)
+torch.cuda.synchronize()
+torch.save({"dq": dq.cpu(), "dk": dk.cpu(), "dv": dv.cpu()}, sys.argv[1])
+"""
+
+
+def test_attn_backward_wide_dh64_forms_equal_the_one_block_kernels(dev, tmp_path):
+    """attn_bwd64w.hip (one wave per SIMD, two lane-owned blocks per wave): dQ is on by default, dK / dV is off (measured slower); both are
+    the same arithmetic in the same summation order as attn_bwd.hip's one-block kernels, so every form must give the same gradients to the
+    last place - ragged batch, tails past the last full 256-row block, a sequence of exactly one block, a ragged last streamed tile.  The form is chosen once
+    per process (ACAI_ATTN64_BWD_WIDE), hence the child processes, one after the other."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in ("0", "1", "2", "3"):
+        f = tmp_path / f"w{mode}.pt"
+        env = dict(os.environ, ACAI_ATTN64_BWD_WIDE=mode, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        r = subprocess.run([sys.executable, "-c", _BWD64W_SNIPPET, str(f)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = torch.load(f)
+    for mode in ("1", "2", "3"):
+        for n in ("dq", "dk", "dv"):
+            a, b = outs["0"][n].float(), outs[mode][n].float()
+            # full streamed tiles give the same bits (tools/dbg_bwd64w.py); in a ragged last tile the one-block kernels' general loop forms
+            # 2^(c s - lse) from a zero-started accumulator where these start the accumulator at -lse: a last-place difference in a few elements
+            d = (a - b).abs()
+            assert float(d.max()) <= 2.0 ** -7 * float(a.abs().max()) and float((d > 0).float().mean()) < 2e-3, (mode, n, float(d.max()), float((d > 0).float().mean()))
+    assert float(outs["0"]["dq"].float().abs().max()) < 6.0   # (every row was written: the 7.0 fill is gone)
 
 
 @pytest.mark.parametrize("H,dh,S,B", [(16, 32, 4096, 2), (12, 64, 4096, 1)])
