@@ -96,6 +96,7 @@ _SIGNATURES = {
     "acai_decode_sample_step": (c_int, [POINTER(AcaiDecoder), c_void_p, c_int, c_float, c_void_p]),
     "acai_decode_logits": (c_int, [POINTER(AcaiDecoder), c_void_p, c_int, c_void_p]),
     "acai_decode_hidden": (c_int, [POINTER(AcaiDecoder), c_void_p, c_void_p]),
+    "acai_decode_merge_in_launch": (c_int, [c_int, c_int]),
     "acai_graph_begin": (c_int, [c_void_p]),
     "acai_graph_end": (c_int, [c_void_p, POINTER(c_void_p)]),
     "acai_graph_launch": (c_int, [c_void_p, c_void_p]),

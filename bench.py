@@ -622,6 +622,16 @@ def dry_run(a):
         dist.destroy_process_group()
 
 
+def _split_merge_path():
+    """Which way the decode step merges its attention splits on this box (acai_decode_merge_in_launch): a silent change of path is a 3 % change
+    of the headline."""
+    try:
+        from acai_omr_amd import _lib
+        return "in-launch" if _lib.lib().acai_decode_merge_in_launch(_lib.ACAI_BF16, 64) == 1 else "separate combine launch"
+    except Exception as e:   # (never costs the line)
+        return f"unknown ({type(e).__name__})"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -800,7 +810,8 @@ def main():
         out = dict(metric="LMX tokens/sec (greedy decode, KV cache)", value=tokens / dt, unit="tokens/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
                    ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
                    config=dict(workload=f"vitomr_greedy_decode batch {a.batch}/GPU of {a.height}x{a.width} images ({S} patches), decode steps {a.warmup + 1}..{a.warmup + a.steps}" + ("" if a.warmup + a.steps <= cap else f" (re-armed every {cap} steps)"),
-                               batch_per_gpu=a.batch, memory_len=S, decoder="12 x d1024 h16 mlp4096, V=227", hipgraph=use_graph),
+                               batch_per_gpu=a.batch, memory_len=S, decoder="12 x d1024 h16 mlp4096, V=227", hipgraph=use_graph,
+                               split_merge=_split_merge_path()),
                    prefill_ms=prefill_s * 1e3, prefill_encoder_dtype=a.encoder_dtype, roofline=roof, cpu_baseline=cpu, mae=mae_res, tf_step=tf_res,
                    ragged_decode=rag_res, config5=c5_res, dist=dinfo,
                    value_steps256=(tokens / dt if a.steps == 256 else world * a.batch * 256 / dt256))

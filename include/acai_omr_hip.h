@@ -271,6 +271,12 @@ int acai_decode_logits(const AcaiDecoder *dec, const int64_t *tokens, int time_s
  * the L cached layers and the optional final norm lands in dec->xn.  emb / pos / unembed may be NULL for this call. */
 int acai_decode_hidden(const AcaiDecoder *dec, const float *x_in, void *stream);
 
+/* 1 when a decode step with `dec->tickets` set merges the split partials of its attention launches inside those launches (last-arriver
+ * hand-off), 0 when it takes the separate combine launch instead (tickets ignored: the hand-off is used only at the workgroup residency it
+ * was validated at, or as ACAI_DATTN_MERGE forces), negative for a bad argument.  Same arithmetic either way (kv_caching.py:131 - the SDPA
+ * of a cached step); bench.py reports it so that a silent change of path shows in the headline line. */
+int acai_decode_merge_in_launch(int dtype, int dhp);
+
 /* F.linear on a (B,1,K) activation (K:193,215; nn.Linear inside cached_forward K:139,222): y[B,N] = x[B,K].W[N,K]^T
  * + bias (+GELU) (+residual); x, y, bias, residual fp32, W in `dtype` (bf16: x is rounded to bf16 first, as autocast does). */
 int acai_skinny_gemm(const float *x, int ldx, const void *W, int ldw, const float *bias, const float *residual, int ldr,

@@ -4,6 +4,8 @@
 Bars: fp32 path - bit-exact greedy token ids, logits within 1e-3 (SURVEY section 0);
       bf16 (autocast plumbing) path - token ids equal to the reference's bf16-autocast run on these fixtures,
       logits within bf16 resolution of the oracle's autocast restatement (same rounding points)."""
+import os
+
 import pytest
 import torch
 from torch.amp import autocast
@@ -523,6 +525,19 @@ def test_decode_is_deterministic_run_to_run(dev):
             outs.append((seqs.clone(), lps.clone()))
     for o in outs[1:]:
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+
+
+def test_decode_split_merge_runs_in_launch_on_this_toolchain(dev):
+    """The headline decode step merges its attention splits inside the attention launches (decode.hip, last-arriver hand-off) only at the
+    workgroup residency it was validated at; otherwise it silently takes a separate combine launch (12 more launches per step: 0.712 against
+    0.689 ms - round 4 shipped that way for a while because the check compared the occupancy API's answer with the wrong number).  On this
+    pool's toolchain the validated path must be the one in use; a red test here after a ROCm upgrade means: re-run the determinism test and
+    tools/soak_decode.py at the new residency (ACAI_DATTN_MERGE=1), then update dattn_merge_validated()."""
+    from acai_omr_amd import _lib
+    if os.environ.get("ACAI_DATTN_MERGE") is not None:
+        pytest.skip("path forced by ACAI_DATTN_MERGE")
+    assert _lib.lib().acai_decode_merge_in_launch(_lib.ACAI_BF16, 64) == 1
+    assert _lib.lib().acai_decode_merge_in_launch(_lib.ACAI_BF16, 3) < 0      # argument check (dhp must be a power of two)
 
 
 def test_full_size_batch_independence_of_decode(dev):

@@ -12,8 +12,13 @@ for d in sorted(glob.glob(os.path.join(root, "pmc*_*"))):
             if "attn_" not in k:
                 continue
             m = re.search(r"(attn_\w+)<([^>]*)>", k)
-            short = m.group(1) + "<" + m.group(2).replace("unsigned short", "bf16") + ">" if m else k[:60]
+            short = m.group(1) + "<" + m.group(2).replace("unsigned short", "bf16") + ">" if m else re.sub(r"\(anonymous namespace\)::", "", k).split("(")[0][:60]
             acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            acc[short]["dur_us"].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
     print("==", os.path.basename(d))
     for k, cs in acc.items():
-        print("  ", k, {c.replace("SQ_", ""): f"{sum(v) / len(v):.4g}" for c, v in sorted(cs.items())}, "n=", len(next(iter(cs.values()))))
+        mean = {c: sum(v) / len(v) for c, v in cs.items()}
+        extra = {}
+        if "GRBM_GUI_ACTIVE" in mean:   # effective clock (MI355X_MICROARCH.md, DVFS give-back): the counter is summed over the 8 XCDs
+            extra["clock_GHz"] = f"{mean['GRBM_GUI_ACTIVE'] / 8 / (mean['dur_us'] * 1e3):.3f}"
+        print("  ", k, {c.replace("SQ_", ""): f"{v:.4g}" for c, v in sorted(mean.items())}, extra, "n=", len(next(iter(cs.values()))))
