@@ -178,6 +178,93 @@ def test_config3_teacher_forced_bf16_step_at_size_vs_oracle(dev):
         assert r < 2e-2 and c > 0.9999, (n, r, c)            # measured 3e-3 ... 5e-3, cosine 0.999996
 
 
+# ---- configs 2 and 3 at their BATCH sizes: a size-independent property instead of the (too slow) CPU oracle ---------------------------------
+def _grads(model, names):
+    ps = dict(model.named_parameters())
+    return {n: ps[n].grad.detach().float().clone() for n in names}
+
+
+def test_config2_full_batch_of_32_equals_its_two_halves(dev):
+    """BASELINE config 2 at its batch size (32 x 512 x 2048, bf16 autocast, full-size MAE): the at-size test above runs ONE image against the
+    oracle; the batch-level mechanisms (131072-row decoder GEMMs in their persistent ping-pong forms, 32-sequence attention grids, the loss's
+    batch-global denominator) are pinned here by linearity - the gradient of the batch-of-32 loss equals the mean of the two half-batch
+    gradients (every image masks the same number of patches, so the halves weigh equally), and the loss likewise."""
+    from acai_omr_amd.config import MASK_RATIO, PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH
+    from acai_omr_amd.models.models import MAE, MAELoss
+    torch.manual_seed(12)
+    mae = MAE(MASK_RATIO, PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH)
+    _perturb(mae)
+    mae = mae.to(dev).train()
+    g = torch.Generator().manual_seed(13)
+    imgs = [torch.rand(1, 512, 2048, generator=g).to(dev) for _ in range(32)]
+    noise = [torch.rand(4096, generator=g) for _ in range(32)]
+    names = ("decoder_unembed.weight", "decoder.decoder_blocks.layers.7.linear1.weight", "decoder.decoder_blocks.layers.0.self_attn.in_proj_weight",
+             "encoder.encoder_blocks.layers.0.self_attn.in_proj_weight", "mask_token", "encoder.projection.weight")
+
+    def step(lo, hi):
+        mae.zero_grad(set_to_none=True)
+        with autocast(device_type="cuda", dtype=torch.bfloat16):
+            pred, loss_mask, target, _ = mae.forward_packed([(im, im) for im in imgs[lo:hi]], noises=noise[lo:hi])
+        loss = MAELoss()(pred, loss_mask, target)
+        loss.backward()
+        return float(loss.detach()), _grads(mae, names)
+
+    l_full, g_full = step(0, 32)
+    l_a, g_a = step(0, 16)
+    l_b, g_b = step(16, 32)
+    assert abs(l_full - 0.5 * (l_a + l_b)) < 2e-4 * max(1.0, abs(l_full)), (l_full, l_a, l_b)
+    for n in names:
+        ref = 0.5 * (g_a[n] + g_b[n])
+        r, c = relerr(g_full[n], ref), cosine(g_full[n], ref)
+        print(f"config2 batch 32 vs 2 x 16: grad {n}: rel max err {r:.3e} cosine {c:.6f}")
+        assert r < 1e-2 and c > 0.99995, (n, r, c)           # measured 3e-7 ... 2e-6 (an image's rows never meet another image's)
+
+
+def test_config3_full_batch_of_16_equals_its_two_halves(dev):
+    """BASELINE config 3 at its batch size (16 systems of 512 x 2048 with 512 LMX tokens + <bos>: the 16 x 513 = 8208-row decoder stream with
+    its one-row tails - GEMM tiles of 8208 rows, the 513th token's attention tail kernels, the 65536-token encoder stream), full-size
+    ScheduledSamplingViTOMR.forward_train(tf_prob = 1) under autocast(bf16): the gradient of the batch loss equals the token-count-weighted
+    mean of the two half-batch gradients (4104-row streams: different tile counts, ragged tails and split-K factors for the same arithmetic)."""
+    from acai_omr_amd.config import ENCODER_FINE_TUNE_DEPTH, MAX_LMX_SEQ_LEN, NUM_DECODER_LAYERS, PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH
+    from acai_omr_amd.models.models import FineTuneOMREncoder, OMRCELoss, OMRDecoder, ScheduledSamplingViTOMR
+    torch.manual_seed(14)
+    enc = FineTuneOMREncoder(PATCH_SIZE, PE_MAX_HEIGHT, PE_MAX_WIDTH, ENCODER_FINE_TUNE_DEPTH, transformer_dropout=0.0)
+    dec = OMRDecoder(MAX_LMX_SEQ_LEN, VOCAB, num_layers=NUM_DECODER_LAYERS, transformer_dropout=0.0)
+    m = ScheduledSamplingViTOMR(enc, None, dec, transition_head_dropout=0.0)
+    _perturb(m, unembed_scale=3.0)
+    m = m.to(dev).train()
+    g = torch.Generator().manual_seed(15)
+    T = 512
+    batch = []
+    for i in range(16):
+        n_tok = T - 1 if i % 5 else T - 1 - 37 * (i // 5 + 1)        # mostly full-length sequences, a few shorter ones (pad columns in the batch)
+        batch.append((torch.rand(1, 512, 2048, generator=g).to(dev),
+                      torch.cat([torch.tensor([0]), torch.randint(3, 227, (n_tok,), generator=g), torch.tensor([2])]).to(dev)))
+    names = ("decoder.unembed.weight", "decoder.decoder_blocks.layers.0.multihead_attn.in_proj_weight", "decoder.decoder_blocks.layers.11.linear2.weight",
+             "decoder.decoder_blocks.layers.5.self_attn.in_proj_weight", "transition_head.0.weight", "encoder.fine_tune_blocks.layers.11.linear1.weight",
+             "encoder.fine_tune_blocks.layers.0.self_attn.in_proj_weight")
+
+    def step(lo, hi):
+        m.zero_grad(set_to_none=True)
+        with autocast(device_type="cuda", dtype=torch.bfloat16):
+            pred, tgt = m.forward_train(batch[lo:hi], 1.0, 0.5, False)
+            loss = OMRCELoss(m.decoder.pad_idx)(pred, tgt)
+        loss.backward()
+        return float(loss.detach()), int((tgt != m.decoder.pad_idx).sum()), _grads(m, names)
+
+    l_full, n_full, g_full = step(0, 16)
+    l_a, n_a, g_a = step(0, 8)
+    l_b, n_b, g_b = step(8, 16)
+    assert n_full == n_a + n_b
+    wa, wb = n_a / n_full, n_b / n_full
+    assert abs(l_full - (wa * l_a + wb * l_b)) < 5e-4 * max(1.0, abs(l_full)), (l_full, l_a, l_b)
+    for n in names:
+        ref = wa * g_a[n] + wb * g_b[n]
+        r, c = relerr(g_full[n], ref), cosine(g_full[n], ref)
+        print(f"config3 batch 16 vs 2 x 8: grad {n}: rel max err {r:.3e} cosine {c:.6f}")
+        assert r < 1e-2 and c > 0.99995, (n, r, c)           # measured 1e-4 ... 9e-4 (bf16 roundings of differently split sums), cosine 1.000000
+
+
 # ---- config 5: the single-rank arithmetic of its largest ragged shard shapes ------------------------------------------------------------
 def test_config5_shard_shapes_mae_bf16_step_vs_oracle(dev):
     """BASELINE config 5 deals 768 x 3072 images (N = 9216 patches) to every rank; no other test ran a training BACKWARD beyond N = 4096.
