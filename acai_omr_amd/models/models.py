@@ -402,7 +402,7 @@ class OMRDecoder(nn.Module):
             raise ValueError(f"{T} long lmx sequence length is too long for max sequence length of {self.max_lmx_seq_len}")
         if _training_path_needed(self) or (torch.is_grad_enabled() and (img_latent.requires_grad or (not token_idxs_input and input_seqs.requires_grad))):
             from ..train import autograd_path
-            return autograd_path.decoder_forward(self, input_seqs, img_latent, lmx_attention_mask, latent_attention_mask, token_idxs_input)
+            return autograd_path.decoder_forward(self, input_seqs, img_latent, lmx_attention_mask, latent_attention_mask, token_idxs_input, checkpoint_grads)
         dev = self.pos_embedding.device
         B = input_seqs.shape[0]
         lens_t = [T] * B if lmx_attention_mask is None else (~lmx_attention_mask).sum(dim=1).tolist()

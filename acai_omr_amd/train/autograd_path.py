@@ -933,7 +933,11 @@ class shared_cross_kv:
         return False
 
 
-def decoder_forward(dec, input_seqs, img_latent, lmx_attention_mask, latent_attention_mask, token_idxs_input=True):
+def decoder_forward(dec, input_seqs, img_latent, lmx_attention_mask, latent_attention_mask, token_idxs_input=True, checkpoint_grads=False):
+    """checkpoint_grads (reference: models.py:470-478, `checkpoint_sequential` with one segment per decoder layer, used by the GRPO loop): each
+    layer's activations are dropped after the forward and recomputed in the backward (torch.utils.checkpoint, non-reentrant; the dropout seeds
+    come from torch's CPU generator, whose state the checkpoint restores for the recomputation).  Same logits and gradients; the cross K / V
+    projection of a layer is part of its checkpointed segment unless it is shared between two passes (then it is computed once, outside)."""
     _check_dropout(dec)
     prec, wc = _prec(), _wc(dec)
     bf = prec == "bf16"
@@ -960,25 +964,34 @@ def decoder_forward(dec, input_seqs, img_latent, lmx_attention_mask, latent_atte
     if share is not None:
         share["mem"] = (mem32, lens_s, memc)
     mt, ms = max(lens_t), max(lens_s)
-    for li, ly in enumerate(dec.decoder_blocks.layers):
+    tr = dec.training
+    pre = _q_prescale(prec, E, dh)
+
+    def layer(ly, x32, memc, kv_shared):
         sa, ca = ly.self_attn, ly.multihead_attn
-        tr = dec.training
         y = _self_attn_block(x32, sa, cu_t, H, mt, True, _p_of(sa, tr), _p_of(ly.dropout1, tr), prec, wc)
         x32 = LayerNormFn.apply(y, ly.norm1.weight, ly.norm1.bias, ly.norm1.eps)
         xc = CastBf16Fn.apply(x32) if bf else x32
-        pre = _q_prescale(prec, E, dh)
         # (the fused parameters go in whole: LinearFn takes its rows through the _SliceCache and writes their gradient into the full-size tensor)
         q = LinearFn.apply(xc, ca.in_proj_weight, ca.in_proj_bias, None, prec, _SliceCache(wc, ca, 0, E), False, (E, ops.QSCALE(dh)) if pre else None)
-        kv = None if share is None else share["kv"].get(li)
-        if kv is None:
-            kv = LinearFn.apply(memc, ca.in_proj_weight, ca.in_proj_bias, None, prec, _SliceCache(wc, ca, E, 3 * E), False)
-            if share is not None:
-                share["kv"][li] = kv
+        kv = kv_shared if kv_shared is not None else LinearFn.apply(memc, ca.in_proj_weight, ca.in_proj_bias, None, prec, _SliceCache(wc, ca, E, 3 * E), False)
         a = CrossAttnFn.apply(q, kv, cu_t, cu_s, H, dh, mt, ms, _p_of(ca, tr), pre)
         y = _proj_residual(a, ca.out_proj.weight, ca.out_proj.bias, x32, _p_of(ly.dropout2, tr), prec, wc)
         x32 = LayerNormFn.apply(y, ly.norm2.weight, ly.norm2.bias, ly.norm2.eps)
         y = _mlp(x32, ly.linear1, ly.linear2, _p_of(ly.dropout, tr), _p_of(ly.dropout3, tr), prec, wc)
-        x32 = LayerNormFn.apply(y, ly.norm3.weight, ly.norm3.bias, ly.norm3.eps)
+        return LayerNormFn.apply(y, ly.norm3.weight, ly.norm3.bias, ly.norm3.eps)
+
+    use_ckpt = checkpoint_grads and torch.is_grad_enabled()
+    if use_ckpt:
+        from torch.utils.checkpoint import checkpoint
+    for li, ly in enumerate(dec.decoder_blocks.layers):
+        kv = None
+        if share is not None:   # two passes over one memory (scheduled sampling): the projection runs once, outside any checkpointed segment
+            kv = share["kv"].get(li)
+            if kv is None:
+                ca = ly.multihead_attn
+                kv = share["kv"][li] = LinearFn.apply(memc, ca.in_proj_weight, ca.in_proj_bias, None, prec, _SliceCache(wc, ca, E, 3 * E), False)
+        x32 = checkpoint(layer, ly, x32, memc, kv, use_reentrant=False) if use_ckpt else layer(ly, x32, memc, kv)
     nrm = dec.decoder_blocks.norm
     x32 = LayerNormFn.apply(x32, nrm.weight, nrm.bias, nrm.eps)
     logits = _lin(x32, dec.unembed.weight, dec.unembed.bias, prec, wc, out_fp32=True)

@@ -444,6 +444,39 @@ def test_training_with_dropout_runs_and_is_seeded(dev):
     assert abs(float(OMRCELoss(1)(pred, tgt)) - float(fx["loss"])) < 1e-4   # ... and eval mode is the reference's deterministic value
 
 
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_decoder_checkpoint_grads_same_logits_and_gradients(dev, dropout):
+    """OMRDecoder.forward(..., checkpoint_grads=True) (reference models.py:470-478: checkpoint_sequential, one segment per layer; the GRPO
+    loop's setting): the per-layer recomputation must give the logits and every gradient of the plain forward - with dropout too (the masks
+    are a hash of seeds drawn from torch's CPU generator, whose state the checkpoint restores)."""
+    from acai_omr_amd.models.models import OMRDecoder
+    torch.manual_seed(31)
+    dec = OMRDecoder(64, VOCAB, num_layers=3, hidden_dim=128, num_heads=4, mlp_dim=256, transformer_dropout=dropout).to(dev).train()
+    g = torch.Generator().manual_seed(32)
+    B, T, S = 3, 20, 37
+    seqs = torch.randint(3, 227, (B, T), generator=g).to(dev)
+    lmx_mask = torch.zeros(B, T, dtype=torch.bool)
+    lmx_mask[1, 15:] = True
+    mem_mask = torch.zeros(B, S, dtype=torch.bool)
+    mem_mask[2, 30:] = True
+    mem0 = torch.randn(B, S, 128, generator=g)
+    outs = []
+    for ck in (False, True):
+        torch.manual_seed(33)
+        dec.zero_grad(set_to_none=True)
+        mem = mem0.clone().to(dev).requires_grad_(True)
+        logits = dec(seqs, mem, lmx_mask.to(dev), mem_mask.to(dev), checkpoint_grads=ck)
+        w = torch.randn(logits.shape, generator=torch.Generator().manual_seed(34)).to(dev)
+        (logits.float() * w * (~lmx_mask.to(dev)).unsqueeze(-1)).sum().backward()
+        outs.append((logits.detach().float().clone(), mem.grad.clone(), {n: p.grad.clone() for n, p in dec.named_parameters() if p.grad is not None}))
+    (l0, m0, g0), (l1, m1, g1) = outs
+    assert torch.equal(l0, l1)
+    assert set(g0) == set(g1) and len(g0) > 30
+    assert float((m0 - m1).abs().max()) <= 1e-5 * max(1.0, float(m0.abs().max()))
+    for n in g0:
+        assert float((g0[n] - g1[n]).abs().max()) <= 2e-5 * max(1.0, float(g0[n].abs().max())), n     # (split-K float atomics: equal to rounding)
+
+
 @pytest.mark.parametrize("dim", [256, 512, 768, 1024, 96])
 def test_layernorm_bwd_fused_and_colsum_vec(dev, dim):
     """The one-pass LayerNorm backward (dim % 256 == 0) and the generic two-kernel form against torch autograd; bf16 side copy; 16-byte colsum."""
