@@ -6,7 +6,7 @@ import torch
 if sys.argv[1] == "run":
     from acai_omr_amd import engine, ops
     lq, lk, H = (int(x) for x in sys.argv[3:6]) if len(sys.argv) > 5 else (256, 400, 1)
-    dev, bf, dh = "cuda", torch.bfloat16, 64
+    dev, bf, dh = "cuda", torch.bfloat16, int(sys.argv[6]) if len(sys.argv) > 6 else 64
     E = H * dh
     g = torch.Generator().manual_seed(1)
     q = (torch.randn(lq, E, generator=g) * ops.QSCALE(dh)).to(dev).to(bf)
