@@ -581,11 +581,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((sizeof(T) 
                 if constexpr (FAST) {
                     if (d0 < dh) {
                         if constexpr (ES == 2) {
+                            float gk[4], gv[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                gk[e] = dkacc[d][4 * g4 + e] * ksc;
+                                gv[e] = dvacc[d][4 * g4 + e];
+                            }
+                            if (a.accum_dkv) {   // += : the gradient another pass over the same K / V left here (added in fp32, one rounding)
+                                const uint2 ok = *reinterpret_cast<const uint2 *>(rk + d0), ov = *reinterpret_cast<const uint2 *>(rv + d0);
+                                gk[0] += __uint_as_float(ok.x << 16); gk[1] += __uint_as_float(ok.x & 0xffff0000u);
+                                gk[2] += __uint_as_float(ok.y << 16); gk[3] += __uint_as_float(ok.y & 0xffff0000u);
+                                gv[0] += __uint_as_float(ov.x << 16); gv[1] += __uint_as_float(ov.x & 0xffff0000u);
+                                gv[2] += __uint_as_float(ov.y << 16); gv[3] += __uint_as_float(ov.y & 0xffff0000u);
+                            }
                             uint2 pk, pv;
-                            pk.x = pack_bf16(dkacc[d][4 * g4 + 0] * ksc, dkacc[d][4 * g4 + 1] * ksc);
-                            pk.y = pack_bf16(dkacc[d][4 * g4 + 2] * ksc, dkacc[d][4 * g4 + 3] * ksc);
-                            pv.x = pack_bf16(dvacc[d][4 * g4 + 0], dvacc[d][4 * g4 + 1]);
-                            pv.y = pack_bf16(dvacc[d][4 * g4 + 2], dvacc[d][4 * g4 + 3]);
+                            pk.x = pack_bf16(gk[0], gk[1]);
+                            pk.y = pack_bf16(gk[2], gk[3]);
+                            pv.x = pack_bf16(gv[0], gv[1]);
+                            pv.y = pack_bf16(gv[2], gv[3]);
                             *reinterpret_cast<uint2 *>(rk + d0) = pk;
                             *reinterpret_cast<uint2 *>(rv + d0) = pv;
                         } else {
@@ -925,6 +938,7 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, bool pre, hipStrea
     constexpr int RP = TileLayout<ES, DHP>::PITCH;
     const size_t lds_dq = 2 * (2 * TT * RP), lds_dkv = 2 * (2 * TT * RP + 2 * TT * sizeof(float));   // two stages each
     if (pre && !fast) return acai_set_err(-1, "acai_attn_varlen_bwd: q_prescaled needs 16-byte aligned operands and d_h %% %d == 0", EPC);
+    if (a.accum_dkv && !(ES == 2 && fast)) return acai_set_err(-1, "acai_attn_varlen_bwd: accumulating dk / dv needs bf16 and 16-byte aligned operands");
     auto launch_pair = [&](auto drop, auto fst, auto pr) {
         constexpr bool D = decltype(drop)::value, F = decltype(fst)::value, P = decltype(pr)::value;
         static bool attr[ACAI_MAX_DEV] = {};  // one latch per instantiation and device
@@ -941,7 +955,7 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, bool pre, hipStrea
                 hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
                 hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             }
-            if (nq_env == 2 && !a.causal && max_q >= 512 && max_k >= 512) {
+            if (nq_env == 2 && !a.causal && !a.accum_dkv && max_q >= 512 && max_k >= 512) {
                 hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(cdiv(max_q, 2 * OB), a.H, B), dim3(256), lds_dq, st, a);
                 hipLaunchKernelGGL(attn_bwd_dkv2_kernel, dim3(cdiv(max_k, 2 * OB), a.H, B), dim3(256), lds_dkv, st, a);
                 return;
@@ -960,7 +974,7 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, bool pre, hipStrea
             // re-reads its operands from LDS, 1.82 PF from registers) - see DESIGN.md section 9.
             static const int wide_env = getenv("ACAI_ATTN64_BWD_WIDE") ? atoi(getenv("ACAI_ATTN64_BWD_WIDE")) : 1;
             if (wide_env && !a.causal && a.dh == 64) {
-                const bool wq = (wide_env & 1) && max_q >= 256, wk = (wide_env & 2) && max_k >= 256;
+                const bool wq = (wide_env & 1) && max_q >= 256, wk = (wide_env & 2) && max_k >= 256 && !a.accum_dkv;
                 // when every sequence is max_q long (B * max_q rows in all) the host knows whether a tail exists; keys: only for self-attention
                 const bool eq_q = (long long)B * max_q == (long long)a.total_q, eq_k = eq_q && a.cu_k == a.cu_q && max_k == max_q;
                 BwdArgs t = a;
@@ -1008,7 +1022,8 @@ extern "C" int acai_attn_varlen_bwd(const void *q, int ldq, const void *k, int l
     BwdArgs a{};
     a.q = q; a.k = k; a.v = v; a.o = o; a.dout = dout; a.dq = dq; a.dk = dk; a.dv = dv; a.lse = lse; a.delta = delta; a.cu_q = cu_q; a.cu_k = cu_k;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
-    a.H = H; a.dh = dh; a.causal = causal; a.total_q = total_q;
+    ACAI_CHECK_ARG((causal & ~3) == 0, "acai_attn_varlen_bwd: causal takes bit 0 (causal mask) and bit 1 (accumulate dk / dv)");
+    a.H = H; a.dh = dh; a.causal = causal & 1; a.accum_dkv = (causal >> 1) & 1; a.total_q = total_q;
     ACAI_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "acai_attn_varlen_bwd: dropout_p out of range");
     a.drop_thr = (uint32_t)((double)dropout_p * 4294967296.0); a.drop_seed = dropout_seed; a.drop_scale = 1.0f / (1.0f - dropout_p);
     a.scale = 1.0f / sqrtf((float)dh);

@@ -12,6 +12,7 @@ struct BwdArgs {
     float scale_log2e, scale;
     uint32_t drop_thr, drop_seed;  // the forward's attention-probability dropout, regenerated element-wise
     float drop_scale;
+    int accum_dkv; // 1: dk, dv += instead of = (bf16, aligned operands only): a second pass over the same K / V adds its gradient in the kernel's epilogue
     int tail256;   // attn_bwd.hip one-block kernels: > 0 = cover only the rows past each sequence's last full 256-row block (the full blocks belong to attn_bwd64w.hip)
     int nblk;      // attn_bwd64w.hip: 256-row blocks per (sequence, head) of its one-dimensional, XCD-swizzled grid
 };

@@ -114,6 +114,33 @@ def _pgrad_note(param, g):
     return g
 
 
+# The same for a NON-LEAF tensor with two consumers in one graph (a projected memory attended to by two decoder passes): the gradient tensor the first
+# consumer's backward returned, for the second one to add into.
+_TGRAD = {}
+_KV_GRAD_FUSE = os.environ.get("ACAI_KV_GRAD_FUSE", "1") != "0"   # A/B and test aid
+
+
+def _tgrad_key(t):   # (the saved tensor may come back as another Python object: the memory it names is what identifies it inside one backward pass)
+    return (t.data_ptr(), tuple(t.shape), t.stride(0))
+
+
+def _tgrad_prev(t):
+    tid = torch._C._current_graph_task_id()
+    if tid < 0:
+        return None
+    hit = _TGRAD.get(_tgrad_key(t))
+    return hit[1]() if hit is not None and hit[0] == tid else None
+
+
+def _tgrad_note(t, g):
+    tid = torch._C._current_graph_task_id()
+    if tid >= 0:
+        if len(_TGRAD) > 256:   # (entries of earlier passes)
+            for k in [k for k, v in _TGRAD.items() if v[0] != tid or v[1]() is None]:
+                del _TGRAD[k]
+        _TGRAD[_tgrad_key(t)] = (tid, weakref.ref(g))
+
+
 def _wgrad(W, dy, x):
     """dW = dy^T x (fp32, split-K atomics into a zeroed tensor)."""
     prev = _pgrad_prev(W)
@@ -392,9 +419,21 @@ class CrossAttnFn(Function):
         q, kv, out, lse, cu_q, cu_k = ctx.saved_tensors
         H, dh, max_q, max_k, dropout_p, seed, pre = ctx.cfg
         E = H * dh
-        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        dq = torch.empty_like(q)
+        # Two passes over ONE projected memory (scheduled sampling: decoder_forward shares `kv` between them): the pass whose backward runs second adds
+        # its dK / dV inside the kernel's epilogue to the tensor the first one handed to autograd (which hands it on to the projection's backward only
+        # after both nodes ran) and returns no gradient of its own - instead of autograd summing two [keys, 2E] tensors per layer (12 x ~150 us per
+        # teacher-forced step).  Scoped to the current backward pass, as the in-place parameter gradients are.
+        # (the kernel's accumulate form exists for bf16 with 16-byte aligned rows and head slices only - the condition of its vector path)
+        fusable = _KV_GRAD_FUSE and kv.dtype == torch.bfloat16 and dh % 8 == 0 and kv.stride(0) % 8 == 0 and q.stride(0) % 8 == 0 and kv.stride(1) == 1
+        prev = _tgrad_prev(kv) if fusable else None
+        dkv = prev if prev is not None else torch.empty_like(kv)
         ops.attn_varlen_bwd(q, kv[:, :E], kv[:, E:], out, dout.contiguous().to(q.dtype), lse, cu_q, cu_k, H, dh, max_q, max_k, False,
-                            dq, dkv[:, :E], dkv[:, E:], dropout_p=dropout_p, seed=seed, q_prescaled=pre)
+                            dq, dkv[:, :E], dkv[:, E:], dropout_p=dropout_p, seed=seed, q_prescaled=pre, accumulate_dkv=prev is not None)
+        if prev is not None:
+            return dq, None, None, None, None, None, None, None, None, None
+        if fusable:
+            _tgrad_note(kv, dkv)
         return dq, dkv, None, None, None, None, None, None, None, None
 
 

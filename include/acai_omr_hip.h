@@ -141,7 +141,10 @@ int acai_attn_varlen_fwd(const void *q, int ldq, const void *k, int ldk, const v
  * o / lse are the forward's outputs, dout the incoming gradient; dq/dk/dv take the layout of q/k/v (own row strides).
  * delta: workspace [H][total_q] floats.  Deterministic (no atomics): S and P are recomputed per kernel.
  * q_prescaled != 0: q is the forward's q' (see there); dq is still the gradient with respect to the UNSCALED in-projection output
- * (what the in-projection's backward GEMMs consume), dk and dv are unchanged in meaning. */
+ * (what the in-projection's backward GEMMs consume), dk and dv are unchanged in meaning.
+ * `causal`: bit 0 = the causal mask; bit 1 (round 4) = dk, dv += instead of = (bf16, 16-byte aligned operands): when two passes attend to ONE stored
+ * K / V (ScheduledSamplingViTOMR.forward_train's two decoder passes over the same memory, models.py:822-834) the second pass's backward adds
+ * its gradient in the kernel's epilogue - fp32 add, one rounding - instead of autograd summing two [keys, 2E] tensors afterwards. */
 int acai_attn_varlen_bwd(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, const void *o, int ldo,
                          const void *dout, int lddo, void *dq, int lddq, void *dk, int lddk, void *dv, int lddv, const float *lse,
                          float *delta, const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int max_k,

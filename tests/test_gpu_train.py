@@ -367,6 +367,57 @@ def test_twice_used_parameters_accumulate_in_place(dev):
     assert any(n.startswith("decoder.decoder_blocks.layers.0.norm1") for n in plain)
 
 
+def test_shared_memory_gradient_accumulates_in_the_attention_backward(dev):
+    """Scheduled sampling's two decoder passes attend to ONE projected memory per layer (autograd_path.decoder_forward shares it): under autocast the
+    pass whose backward runs second adds its dK / dV inside the attention backward's epilogue (acai_attn_varlen_bwd, causal bit 1) to the tensor
+    the first one returned, instead of autograd adding two [keys, 2E] tensors.  Same gradients as the plain form (flag off) up to one bf16 rounding
+    of that sum - checked on the parameters the sum flows into (the cross attention's K / V rows, the transition head, the encoder)."""
+    from torch.amp import autocast
+    from acai_omr_amd.models.models import FineTuneOMREncoder, OMRCELoss, OMRDecoder, ScheduledSamplingViTOMR
+    from acai_omr_amd.train import autograd_path as AP
+    torch.manual_seed(41)
+    n_dec = 3
+    enc = FineTuneOMREncoder(16, 8, 8, 2, num_layers=2, hidden_dim=64, num_heads=2, mlp_dim=128, transformer_dropout=0.0)
+    dec = OMRDecoder(32, VOCAB, num_layers=n_dec, hidden_dim=64, num_heads=2, mlp_dim=128, transformer_dropout=0.0)    # d_h = 32: the aligned (vector) kernels
+    m = ScheduledSamplingViTOMR(enc, None, dec, transition_head_dim=96, transition_head_dropout=0.0).to(dev).train()
+    g = torch.Generator().manual_seed(42)
+    batch = [(torch.rand(1, 32, 64, generator=g).to(dev), torch.cat([torch.tensor([0]), torch.randint(3, 227, (n,), generator=g), torch.tensor([2])]).to(dev))
+             for n in (12, 7, 9)]
+    calls = []
+    orig = AP.ops.attn_varlen_bwd
+
+    def spy(*a, **k):
+        calls.append(bool(k.get("accumulate_dkv")))
+        return orig(*a, **k)
+
+    def grads(fuse):
+        AP._KV_GRAD_FUSE = fuse
+        AP.ops.attn_varlen_bwd = spy
+        try:
+            m.zero_grad(set_to_none=True)
+            torch.manual_seed(11)
+            with autocast(device_type="cuda", dtype=torch.bfloat16):
+                pred, tgt = m.forward_train(batch, 0.4, 0.5, False)
+                loss = OMRCELoss(m.decoder.pad_idx)(pred, tgt)
+            loss.backward()
+            return {n: p.grad.float().clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            AP._KV_GRAD_FUSE = True
+            AP.ops.attn_varlen_bwd = orig
+
+    plain = grads(False)
+    assert not any(calls)
+    del calls[:]
+    fused = grads(True)
+    assert sum(calls) == n_dec, (sum(calls), len(calls))     # one accumulating backward per decoder layer's cross attention
+    assert set(plain) == set(fused)
+    for n in plain:
+        a, b = plain[n], fused[n]
+        assert float((a - b).abs().max()) <= 2e-2 * max(1e-3, float(a.abs().max())), n
+        if a.numel() > 64:
+            assert float(torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0)) > 0.9999, n
+
+
 def test_dropout_kernels(dev):
     """Counter-based dropout: keep rate / scaling, forward-backward mask consistency, attention-probability dropout checked against
     finite differences of the forward kernel itself (same seed -> same mask) and in expectation against the undropped output."""
