@@ -202,6 +202,18 @@ def _bgrad(b, dy, cs=None):
 
 
 # ---- autograd Functions ---------------------------------------------------------------------------------------------------
+def _rows_param_grads(W, b, r0, r1, dyc, x, cs, need_w, need_b):
+    """Gradient of rows r0:r1 of a fused parameter (the q or the k / v rows of nn.MultiheadAttention.in_proj_weight / _bias) as full-size tensors."""
+    if _ROWS_DW_FUSE and need_w and need_b and cs is None and dyc.dtype == torch.bfloat16:
+        # both gradients' rows from one pass over dy (ops.gemm_dw), into the full-size tensors of this backward pass
+        pw, pb = _pgrad_prev(W), _pgrad_prev(b)
+        gw = pw if pw is not None else _pgrad_note(W, ops._ZEROS.take(W.shape[0], W.shape[1], W.device))
+        gb = pb if pb is not None else _pgrad_note(b, ops._ZEROS.take(1, b.shape[0], b.device).view(-1))
+        ops.gemm_dw(dyc, x, out=gw[r0:r1], bias_out=gb[r0:r1])
+        return (None if pw is not None else gw), (None if pb is not None else gb)
+    return (_wgrad_rows(W, r0, r1, dyc, x) if need_w else None), (_bgrad_rows(b, r0, r1, dyc, cs) if need_b else None)
+
+
 class LinearFn(Function):
     """y = x @ W^T + b (+ residual).  x in the compute dtype; y fp32 when a residual is added, else compute dtype (or fp32 on request)."""
 
@@ -227,18 +239,7 @@ class LinearFn(Function):
         dyc, cs = _grad_copy_cs(dy, prec)
         dx = ops.gemm_nt(dyc, ctx.wc.wt(W, prec), out_dtype=x.dtype) if ctx.needs_input_grad[0] else None
         if ctx.rows is not None:
-            r0, r1 = ctx.rows
-            need_w, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-            if _ROWS_DW_FUSE and need_w and need_b and cs is None and dyc.dtype == torch.bfloat16:
-                # both gradients' rows from one pass over dy (ops.gemm_dw), into the full-size tensors of this backward pass
-                pw, pb = _pgrad_prev(W), _pgrad_prev(b)
-                gw = pw if pw is not None else _pgrad_note(W, ops._ZEROS.take(W.shape[0], W.shape[1], W.device))
-                gb = pb if pb is not None else _pgrad_note(b, ops._ZEROS.take(1, b.shape[0], b.device).view(-1))
-                ops.gemm_dw(dyc, x, out=gw[r0:r1], bias_out=gb[r0:r1])
-                dW, db = (None if pw is not None else gw), (None if pb is not None else gb)
-            else:
-                dW = _wgrad_rows(W, r0, r1, dyc, x) if need_w else None
-                db = _bgrad_rows(b, r0, r1, dyc, cs) if need_b else None
+            dW, db = _rows_param_grads(W, b, ctx.rows[0], ctx.rows[1], dyc, x, cs, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
         else:
             dW, db = _wbgrad(W, b, dyc, x, cs, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
         return dx, dW, db, dres, None, None, None, None
@@ -278,7 +279,8 @@ class MlpFn(Function):
     (nor the bf16 -> fp32 copy in front of it)."""
 
     @staticmethod
-    def forward(ctx, x32, W1, b1, W2, b2, prec, wc):
+    def forward(ctx, x32, W1, b1, W2, b2, prec, wc, has_res=True):
+        """has_res = False: y = linear2(GELU(linear1(x))) in the compute dtype, no residual (the transition head, models.py:669-670)."""
         bf = prec == "bf16"
         cdt = torch.bfloat16 if bf else torch.float32
         x = _compute_copy(x32, prec)
@@ -290,9 +292,9 @@ class MlpFn(Function):
             h = ops.gemm_nt(x, wc.w(W1, prec), wc.b(b1, prec), out_dtype=cdt, gelu=True, round_bf16=bf, pre_act=a)
         else:
             h = ops.gemm_nt(x, wc.w(W1, prec), wc.b(b1, prec), out_dtype=cdt, gelu=True, round_bf16=bf, gelu_grad_out=a)
-        y = ops.gemm_nt(h, wc.w(W2, prec), wc.b(b2, prec), residual=x32, out_dtype=torch.float32, round_bf16=bf)
+        y = ops.gemm_nt(h, wc.w(W2, prec), wc.b(b2, prec), residual=x32 if has_res else None, out_dtype=torch.float32 if has_res else cdt, round_bf16=bf)
         ctx.save_for_backward(x, a, h, W1, W2, b1, b2)
-        ctx.prec, ctx.wc = prec, wc
+        ctx.prec, ctx.wc, ctx.has_res = prec, wc, has_res
         return y
 
     @staticmethod
@@ -308,9 +310,10 @@ class MlpFn(Function):
         dW2, db2 = _wbgrad(W2, b2, dyc, h, cs, ctx.needs_input_grad[3], ctx.needs_input_grad[4])
         dx = None
         if ctx.needs_input_grad[0]:   # branch gradient (rounded to the compute dtype as the unfused path does) + residual gradient, fp32
-            dx = ops.gemm_nt(da, wc.wt(W1, prec), residual=dy.float() if dy.dtype != torch.float32 else dy, out_dtype=torch.float32, round_bf16=bf)
+            res = (dy.float() if dy.dtype != torch.float32 else dy) if ctx.has_res else None
+            dx = ops.gemm_nt(da, wc.wt(W1, prec), residual=res, out_dtype=torch.float32, round_bf16=bf)
         dW1, db1 = _wbgrad(W1, b1, da, x, None, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
-        return dx, dW1, db1, dW2, db2, None, None
+        return dx, dW1, db1, dW2, db2, None, None, None
 
 
 class SelfAttnBlockFn(Function):
@@ -435,6 +438,55 @@ class CrossAttnFn(Function):
         if fusable:
             _tgrad_note(kv, dkv)
         return dq, dkv, None, None, None, None, None, None, None, None
+
+
+class CrossAttnBlockFn(Function):
+    """y = x + out_proj(SDPA(q_proj(x), kv)) on the fp32 stream x as one autograd node (no dropout), kv = the projected memory [Mk, 2E]: as
+    SelfAttnBlockFn, x has a single consumer - the residual gradient is added in the epilogue of the q projection's dX GEMM, so autograd runs
+    neither its accumulation add nor the bf16 -> fp32 copy in front of it (two launches per decoder layer and pass on the 8208-row stream)."""
+
+    @staticmethod
+    def forward(ctx, x32, kv, Win, bin_, Wo, bo, cu_q, cu_k, H, max_q, max_k, prec, wc, attn_mod):
+        bf = prec == "bf16"
+        cdt = torch.bfloat16 if bf else torch.float32
+        E = x32.shape[1]
+        dh = E // H
+        x = _compute_copy(x32, prec)
+        pre = _q_prescale(prec, E, dh)
+        sl = _SliceCache(wc, attn_mod, 0, E)
+        q = ops.gemm_nt(x, sl.w(Win, prec), sl.b(bin_, prec), out_dtype=cdt, round_bf16=bf, col_scale=(E, ops.QSCALE(dh)) if pre else None)
+        lse = torch.empty(H * x.shape[0], dtype=torch.float32, device=x.device)
+        attn = ops.attn_varlen(q, kv[:, :E], kv[:, E:], cu_q, cu_k, H, dh, max_q, lse=lse, q_prescaled=pre)
+        y = ops.gemm_nt(attn, wc.w(Wo, prec), wc.b(bo, prec), residual=x32, out_dtype=torch.float32, round_bf16=bf)
+        ctx.save_for_backward(x, q, kv, attn, lse, cu_q, cu_k, Win, bin_, Wo, bo)
+        ctx.cfg = (H, dh, max_q, max_k, prec, wc, pre, attn_mod)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, q, kv, attn, lse, cu_q, cu_k, Win, bin_, Wo, bo = ctx.saved_tensors
+        H, dh, max_q, max_k, prec, wc, pre, attn_mod = ctx.cfg
+        bf = prec == "bf16"
+        E = H * dh
+        dy = dy.contiguous()
+        dyc, cs = _grad_copy_cs(dy, prec)
+        dattn = ops.gemm_nt(dyc, wc.wt(Wo, prec), out_dtype=attn.dtype, round_bf16=bf)
+        dWo, dbo = _wbgrad(Wo, bo, dyc, attn, cs, ctx.needs_input_grad[4], ctx.needs_input_grad[5])
+        dq = torch.empty_like(q)
+        # (the second pass over a shared projected memory adds its dK / dV in the kernel's epilogue: see CrossAttnFn.backward)
+        fusable = _KV_GRAD_FUSE and kv.dtype == torch.bfloat16 and dh % 8 == 0 and kv.stride(0) % 8 == 0 and q.stride(0) % 8 == 0 and kv.stride(1) == 1
+        prev = _tgrad_prev(kv) if fusable else None
+        dkv = prev if prev is not None else torch.empty_like(kv)
+        ops.attn_varlen_bwd(q, kv[:, :E], kv[:, E:], attn, dattn, lse, cu_q, cu_k, H, dh, max_q, max_k, False, dq, dkv[:, :E], dkv[:, E:], q_prescaled=pre,
+                            accumulate_dkv=prev is not None)
+        if prev is None and fusable:
+            _tgrad_note(kv, dkv)
+        sl = _SliceCache(wc, attn_mod, 0, E)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm_nt(dq, sl.wt(Win, prec), residual=dy.float() if dy.dtype != torch.float32 else dy, out_dtype=torch.float32, round_bf16=bf)
+        dWin, dbin = _rows_param_grads(Win, bin_, 0, E, dq, x, None, ctx.needs_input_grad[2], ctx.needs_input_grad[3])
+        return dx, (None if prev is not None else dkv), dWin, dbin, dWo, dbo, None, None, None, None, None, None, None, None
 
 
 class DropoutAddFn(Function):
@@ -730,6 +782,10 @@ def head_forward(head, x):
     prec, wc = _prec(), _wc(head)
     shp = x.shape
     x2 = x.reshape(-1, shp[-1]).float()
+    if _FUSED_MLP and _p_of(head[2], head.training) <= 0.0 and head[0].bias is not None and head[3].bias is not None and x2.dtype == torch.float32:
+        # no dropout between them: Linear -> GELU -> Linear as ONE node, the GELU (and its derivative, kept for the backward) in the first GEMM's epilogue
+        y = MlpFn.apply(x2, head[0].weight, head[0].bias, head[3].weight, head[3].bias, prec, wc, False)
+        return y.view(*shp[:-1], y.shape[-1])
     a = _lin(x2, head[0].weight, head[0].bias, prec, wc)
     h = GeluFn.apply(a)
     if _p_of(head[2], head.training) > 0:
@@ -1010,12 +1066,15 @@ def decoder_forward(dec, input_seqs, img_latent, lmx_attention_mask, latent_atte
         sa, ca = ly.self_attn, ly.multihead_attn
         y = _self_attn_block(x32, sa, cu_t, H, mt, True, _p_of(sa, tr), _p_of(ly.dropout1, tr), prec, wc)
         x32 = LayerNormFn.apply(y, ly.norm1.weight, ly.norm1.bias, ly.norm1.eps)
-        xc = CastBf16Fn.apply(x32) if bf else x32
         # (the fused parameters go in whole: LinearFn takes its rows through the _SliceCache and writes their gradient into the full-size tensor)
-        q = LinearFn.apply(xc, ca.in_proj_weight, ca.in_proj_bias, None, prec, _SliceCache(wc, ca, 0, E), False, (E, ops.QSCALE(dh)) if pre else None)
         kv = kv_shared if kv_shared is not None else LinearFn.apply(memc, ca.in_proj_weight, ca.in_proj_bias, None, prec, _SliceCache(wc, ca, E, 3 * E), False)
-        a = CrossAttnFn.apply(q, kv, cu_t, cu_s, H, dh, mt, ms, _p_of(ca, tr), pre)
-        y = _proj_residual(a, ca.out_proj.weight, ca.out_proj.bias, x32, _p_of(ly.dropout2, tr), prec, wc)
+        if _FUSED_MLP and _p_of(ca, tr) <= 0.0 and _p_of(ly.dropout2, tr) <= 0.0 and ca.in_proj_bias is not None and ca.out_proj.bias is not None:
+            y = CrossAttnBlockFn.apply(x32, kv, ca.in_proj_weight, ca.in_proj_bias, ca.out_proj.weight, ca.out_proj.bias, cu_t, cu_s, H, mt, ms, prec, wc, ca)
+        else:
+            xc = CastBf16Fn.apply(x32) if bf else x32
+            q = LinearFn.apply(xc, ca.in_proj_weight, ca.in_proj_bias, None, prec, _SliceCache(wc, ca, 0, E), False, (E, ops.QSCALE(dh)) if pre else None)
+            a = CrossAttnFn.apply(q, kv, cu_t, cu_s, H, dh, mt, ms, _p_of(ca, tr), pre)
+            y = _proj_residual(a, ca.out_proj.weight, ca.out_proj.bias, x32, _p_of(ly.dropout2, tr), prec, wc)
         x32 = LayerNormFn.apply(y, ly.norm2.weight, ly.norm2.bias, ly.norm2.eps)
         y = _mlp(x32, ly.linear1, ly.linear2, _p_of(ly.dropout, tr), _p_of(ly.dropout3, tr), prec, wc)
         return LayerNormFn.apply(y, ly.norm3.weight, ly.norm3.bias, ly.norm3.eps)
