@@ -367,6 +367,50 @@ def test_twice_used_parameters_accumulate_in_place(dev):
     assert any(n.startswith("decoder.decoder_blocks.layers.0.norm1") for n in plain)
 
 
+def test_attn_backward_accumulate_dkv_flag(dev):
+    """acai_attn_varlen_bwd, `causal` bit 1: dk, dv += instead of =.  Two backward calls with different incoming gradients, the second accumulating,
+    equal the sum of the two plain calls (added in fp32, rounded once: at most one bf16 place from the sum of the two rounded results); dq is
+    written, not accumulated; fp32 operands and stray flag bits are refused with an argument error."""
+    from acai_omr_amd import _lib, engine, ops
+    H, dh, lens_q, lens_k = 2, 64, [300, 513], [700, 260]
+    E = H * dh
+    g = torch.Generator().manual_seed(51)
+    bf = torch.bfloat16
+    q = (torch.randn(sum(lens_q), E, generator=g) * ops.QSCALE(dh)).to(dev).to(bf)
+    k, v = (torch.randn(sum(lens_k), E, generator=g).to(dev).to(bf) for _ in range(2))
+    d1, d2 = (torch.randn(sum(lens_q), E, generator=g).to(dev).to(bf) for _ in range(2))
+    cu_q, cu_k = engine.cu_from_lens(lens_q, dev), engine.cu_from_lens(lens_k, dev)
+    lse = torch.empty(H * sum(lens_q), device=dev)
+    o = ops.attn_varlen(q, k, v, cu_q, cu_k, H, dh, max(lens_q), lse=lse, q_prescaled=True)
+
+    def bwd(dout, dk, dv, acc):
+        dq = torch.empty_like(q)
+        ops.attn_varlen_bwd(q, k, v, o, dout, lse, cu_q, cu_k, H, dh, max(lens_q), max(lens_k), False, dq, dk, dv, q_prescaled=True, accumulate_dkv=acc)
+        return dq
+
+    k1, v1, k2, v2 = (torch.empty_like(k) for _ in range(4))
+    q1 = bwd(d1, k1, v1, False)
+    q2 = bwd(d2, k2, v2, False)
+    ka, va = k1.clone(), v1.clone()
+    q2a = bwd(d2, ka, va, True)
+    assert torch.equal(q2a, q2)
+    for got, a, b in ((ka, k1, k2), (va, v1, v2)):
+        ref = a.float() + b.float()
+        assert float((got.float() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+        assert float((got.float() - ref).abs().mean()) <= 2.0 ** -9 * float(ref.abs().mean()) * 2
+    # refused: fp32 operands, unknown flag bits
+    qf, kf, vf, of, df = (t.float() for t in (q, k, v, o, d1))
+    with pytest.raises(RuntimeError, match="accumulating dk / dv"):
+        ops.attn_varlen_bwd(qf, kf, vf, of, df, lse, cu_q, cu_k, H, dh, max(lens_q), max(lens_k), False, torch.empty_like(qf), torch.empty_like(kf),
+                            torch.empty_like(vf), accumulate_dkv=True)
+    delta = torch.empty(H * sum(lens_q), device=dev)
+    dq = torch.empty_like(q)
+    rc = _lib.lib().acai_attn_varlen_bwd(q.data_ptr(), E, k.data_ptr(), E, v.data_ptr(), E, o.data_ptr(), E, d1.data_ptr(), E, dq.data_ptr(), E, k1.data_ptr(), E,
+                                         v1.data_ptr(), E, lse.data_ptr(), delta.data_ptr(), cu_q.data_ptr(), cu_k.data_ptr(), 2, H, dh, max(lens_q), max(lens_k),
+                                         sum(lens_q), 4, _lib.ACAI_BF16, 0.0, 0, 1, None)
+    assert rc < 0 and b"bit 1" in _lib.lib().acai_last_error()
+
+
 def test_shared_memory_gradient_accumulates_in_the_attention_backward(dev):
     """Scheduled sampling's two decoder passes attend to ONE projected memory per layer (autograd_path.decoder_forward shares it): under autocast the
     pass whose backward runs second adds its dK / dV inside the attention backward's epilogue (acai_attn_varlen_bwd, causal bit 1) to the tensor
