@@ -644,7 +644,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--encoder-dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--mae-batch", type=int, default=32)
-    ap.add_argument("--mae-steps", type=int, default=3)
+    ap.add_argument("--mae-steps", type=int, default=5)
     ap.add_argument("--mae-dtype", default="bf16", choices=["fp32", "bf16"])
     ap.add_argument("--legs", default=None, help="comma list of e2e,b1,mae,tf,ragged,config5 (default: e2e,b1,mae,tf,ragged at N = 1; mae,config5 at N > 1)")
     ap.add_argument("--no-mae", action="store_true")
@@ -840,7 +840,7 @@ def main():
     if "mae" in legs:
         run_leg("mae", bench_mae, dev, rank, world, dist, a.mae_batch, a.height, a.width, a.mae_steps, a.mae_dtype, want_cpu, a.grad_comm_dtype)
     if "tf" in legs and world == 1:
-        run_leg("tf_step", bench_tf_step, dev, 16, a.height, a.width, 512, 2)
+        run_leg("tf_step", bench_tf_step, dev, 16, a.height, a.width, 512, 4)
     if "ragged" in legs and world == 1:
         run_leg("ragged_decode", bench_ragged_decode, dev, 512)
     if "config5" in legs:
