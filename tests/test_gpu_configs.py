@@ -492,7 +492,8 @@ def test_grpo_rollouts_replay_the_reference(dev, name, tag, grouped):
         n = min(ro.shape[1], rro.shape[1])
         same = ro.cpu()[:, :n] == rro[:, :n]
         agree = same.int().cumprod(dim=1).bool()
-        assert float(agree.float().mean()) > 0.7
+        print(f"grpo bf16 replay {name} grouped={grouped}: prefix agreement {float(agree.float().mean()):.3f}, rows identical {int(same.all(dim=1).sum())}/{same.shape[0]}")
+        assert float(agree.float().mean()) > 0.9     # measured 1.000 on every fixture (all rows identical); the slack is for a draw that lands on a CDF step
         live = agree & rmk[:, :n] & mk.cpu()[:, :n]
         d = (lp.cpu()[:, :n] - rlp[:, :n]).abs()[live]
         assert float(d.max()) < 0.07, float(d.max())
