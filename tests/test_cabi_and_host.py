@@ -214,3 +214,41 @@ def test_asm_checks_flag_what_they_are_for():
     assert _asmcheck.check_asm_mfma_operands(spaced) == ([], 1)
     assert _asmcheck.check_asm_mfma_operands(chain) == ([], 2)
     assert _asmcheck.check_asm_mfma_operands("nothing here\n")[0]
+
+
+def test_shared_tensor_gradient_registry_is_scoped_to_one_backward_pass():
+    """autograd_path._tgrad_prev / _tgrad_note (round 4: the second consumer of a shared non-leaf tensor adds its gradient into the tensor the first
+    consumer returned): host logic only, on the CPU with a toy Function - same gradient as plain autograd, one registration per backward pass,
+    nothing reused by a later pass, nothing outside a backward pass."""
+    from acai_omr_amd.train import autograd_path as AP
+
+    adds = []
+
+    class Consumer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t, w):
+            ctx.save_for_backward(t, w)
+            return (t * w).sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            t, w = ctx.saved_tensors
+            prev = AP._tgrad_prev(t)
+            adds.append(prev is not None)
+            if prev is not None:
+                prev.add_(g * w)          # what the kernel's accumulate epilogue does
+                return None, None
+            out = g * w
+            AP._tgrad_note(t, out)
+            return out, None
+
+    assert AP._tgrad_prev(torch.ones(3)) is None          # outside a backward pass: never a hit
+    x = torch.arange(6.0, requires_grad=True)
+    w1, w2 = torch.full((6,), 2.0), torch.full((6,), 5.0)
+    for _ in range(2):                                     # two separate passes: the second must not see the first one's tensor
+        x.grad = None
+        del adds[:]
+        t = x * 3.0                                        # the shared non-leaf tensor
+        (Consumer.apply(t, w1) + Consumer.apply(t, w2)).backward()
+        assert sorted(adds) == [False, True]
+        assert torch.equal(x.grad, torch.full((6,), 3.0 * 7.0))
