@@ -2275,6 +2275,35 @@ int launch(const GemmArgs &g, hipStream_t st) {
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
             return n > 0 ? n : 256;
         }();
+        // A few rows past a multiple of 256 (the teacher-forced decoder stream: 16 x 513 = 8208 = 32 x 256 + 16 rows) can cost a whole round of tiles:
+        // N = 4096 is 528 tiles of 256 x 256 on 256 CUs (three rounds for 2.06 of work: 86 us against 65 at M = 8192), N = 1024 is 520 tiles of
+        // 128 x 128 on 512 resident workgroups (two rounds for 1.02: 33.5 us against 25.7; K = 4096: 99 against 74).  Where the full 256-row part
+        // alone saves such a round, it is launched by itself (the auto rule then picks what it picks for a round number) and the remainder rows
+        // follow as a second, small launch of the same epilogue form (tools/bench_gemm_tf.py).  ACAI_GEMM_SPLIT_REM=0: A/B aid.
+        if constexpr (sizeof(T) == 2 && EPI == 0) {
+            static const bool split_rem = !(getenv("ACAI_GEMM_SPLIT_REM") && atoi(getenv("ACAI_GEMM_SPLIT_REM")) == 0);
+            const int rem = g.M % 256, Mm = g.M - rem;
+            if (split_rem && g_gemm_variant == 0 && rem > 0 && rem <= 32 && Mm >= 4096) {
+                const int nbn256 = cdiv(g.N, 256), full256 = cdiv(g.M, 256) * nbn256, main256 = (Mm / 256) * nbn256;
+                // (measured, tools/bench_gemm_tf.py, M = 8208: N = 4096 90.5 -> 81.5 us, N = 2048 59.7 -> 49.8.  The other case - N = 1024, where the
+                // 8192-row part is exactly one round of 128 x 128 tiles - LOSES: the 16-row remainder takes 16 us at K = 1024 and 46 us at K = 4096 on
+                // the eight workgroups of the generic kernel, 41.7 against 33.5 us and 121 against 101 us in all; it would need a skinny kernel with
+                // the training epilogue forms, so that rule is not applied)
+                const bool saves_round = main256 >= n_cu && cdiv(main256, n_cu) < cdiv(full256, n_cu);
+                if (saves_round) {
+                    const size_t esz = g.out_dtype == ACAI_BF16 ? 2 : 4;
+                    GemmArgs m = g, t = g;
+                    m.M = Mm;
+                    t.M = rem;
+                    t.A = reinterpret_cast<const unsigned char *>(g.A) + (size_t)Mm * g.lda * sizeof(T);
+                    t.C = reinterpret_cast<unsigned char *>(g.C) + (size_t)Mm * g.ldc * esz;
+                    if (g.residual) t.residual = g.residual + (size_t)Mm * g.ldr;
+                    if (g.aux) t.aux = reinterpret_cast<unsigned char *>(g.aux) + (size_t)Mm * g.ldaux * esz;
+                    const int rc = launch<T, EPI, TA, TB>(m, st);
+                    return rc ? rc : launch<T, EPI, TA, TB>(t, st);
+                }
+            }
+        }
         const int nwg4 = cdiv(g.M, 256) * cdiv(g.N, BN), nwg256 = cdiv(g.M, 256) * cdiv(g.N, 256);
         int v = g_gemm_variant;
         bool defer = false;   // variant 8 = 7 with the GELU forms' deferred epilogue (PP_DEFER: measured slower, kept as an experiment - see there)

@@ -532,6 +532,50 @@ def test_gemm_nt_pingpong_epilogues(dev, K, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(8208, 1024, 1024), (8208, 4096, 1024), (8208, 1024, 4096), (16416, 1024, 1024), (4096 + 8, 2048, 1024)])
+def test_gemm_nt_remainder_rows_split_off(dev, shape):
+    """The auto rule launches the rows past a multiple of 256 separately where the full-tile part alone saves a round of tiles (the decoder stream of
+    the teacher-forced step: 16 x 513 = 8208 rows; gemm.hip `split_rem`): every epilogue form the training steps use must come out as from ONE launch of
+    a pinned kernel (variant 6) - the remainder rows above all: their A / C / residual / kept-tensor pointers are advanced by hand."""
+    from acai_omr_amd import _lib, ops
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    bf = torch.bfloat16
+    a = torch.randn(M, K, generator=g).to(dev).to(bf)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev).to(bf)
+    b = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    saved = torch.randn(M, N, generator=g).to(dev).to(bf)
+
+    def run(variant):
+        _lib.check(_lib.lib().acai_gemm_set_variant(variant), "acai_gemm_set_variant")
+        try:
+            out = {}
+            out["plain_bf16"] = ops.gemm_nt(a, w, b, out_dtype=bf, round_bf16=True)
+            out["res_f32"] = ops.gemm_nt(a, w, b, residual=res, round_bf16=True)
+            dgo = torch.full((M, N), 9.0, dtype=bf, device=dev)
+            out["gelu3_bf16"] = ops.gemm_nt(a, w, b, out_dtype=bf, gelu=True, round_bf16=True, gelu_grad_out=dgo)
+            out["dgelu_kept_bf16"] = dgo
+            out["times_bf16"] = ops.gemm_nt(a, w, out_dtype=bf, round_bf16=True, times=saved)
+            out["scale_bf16"] = ops.gemm_nt(a, w, b, out_dtype=bf, round_bf16=True, col_scale=(N // 3 // 4 * 4, ops.QSCALE(64)))
+            torch.cuda.synchronize()
+            return out
+        finally:
+            _lib.lib().acai_gemm_set_variant(0)
+
+    new, old = run(0), run(6)
+    for k in new:
+        for rows in (slice(0, M - M % 256), slice(M - M % 256, M)):      # the full-tile part, the remainder rows
+            x, y = new[k][rows].float(), old[k][rows].float()
+            d = (x - y).abs()
+            if k.endswith("bf16"):
+                assert bool((d <= 2.0 ** -7 * y.abs() + 1e-6).all()), (k, rows, float(d.max()))
+                assert float((d > 0).float().mean()) < 0.01, (k, rows)
+            else:
+                assert bool((d <= 2.0 ** -7 * (y.abs() + 4.0)).all()), (k, rows, float(d.max()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(16384 + 8, 512, 512), (70000, 768, 512), (8192 + 40, 3072 + 24, 768)])
 def test_gemm_nt_pingpong_deferred_gelu(dev, shape):
     """Variant 8: the ping-pong ring with the GELU forms' deferred epilogue (PP_DEFER - the tile boundary stores the bf16 linear output, the
