@@ -964,17 +964,17 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, bool pre, hipStrea
         if constexpr (sizeof(T) == 2 && DHP == 64 && F && !D && P) {
             // the training steps' d_h = 64 form: one wave per SIMD, two lane-owned blocks per wave (attn_bwd64w.hip) over every sequence's full
             // 256-row blocks; the rows past them (none for the encoder's 256-multiples, one for the decoder's 513 tokens) stay with the
-            // one-block kernels below, offset by tail256.  ACAI_ATTN64_BWD_WIDE: 0 off, 1 (default) dQ only, 2 dK/dV only, 3 both.
+            // one-block kernels below, offset by tail256.  ACAI_ATTN64_BWD_WIDE: 0 off, 1 dQ only, 2 dK/dV only, 3 both; unset = auto.
             // Measured (tools/bench_cross_train_attn.py, 16 x 16 heads, same box): the wide dQ form is 1-5 % faster than the one-block kernel
-            // (encoder 4096 x 4096: 1533 against 1561 us; decoder cross 512 x 4096: 184 against 210 us), the wide dK/dV form is SLOWER
-            // (2894 against 2142 us: its 16 more live fragment registers spill to scratch, and a scratch reload's vmcnt(0) also waits for the
-            // staged tile in flight) - both are kept bit-identical to the one-block kernels and tested, only dQ is on.  Why neither gains
-            // what the forward's rebuild did: every d_h = 64 attention kernel already executes 1.03-1.10 PFLOP/s of MFMA work, the rate this
-            // chip sustains at its loaded clock with operands from LDS (tools/experiments/mfma_shape.hip: 1.25 PF for a bare loop that
-            // re-reads its operands from LDS, 1.82 PF from registers) - see DESIGN.md section 9.
-            static const int wide_env = getenv("ACAI_ATTN64_BWD_WIDE") ? atoi(getenv("ACAI_ATTN64_BWD_WIDE")) : 1;
+            // (encoder 4096 x 4096: 1533 against 1561 us; decoder cross 512 x 4096: 184 against 210 us).  The wide dK/dV form is 10 % faster on the
+            // encoder (1886 against 2091 us; 16 x 12 heads: backward 2.51 against 2.63 ms) once its K / V fragments were pinned to the accumulator
+            // half (before that it spilt to scratch and ran 2894 us), but SLOWER where the streamed query loop is short (decoder cross attention,
+            // 513 queries: 9 tiles per workgroup, 663 against 607 us for the pair - one wave per SIMD has nobody to cover a workgroup's prologue):
+            // auto takes it from 2048 streamed queries on.  Why the gains are small: every d_h = 64 attention kernel executes ~1 PFLOP/s of MFMA
+            // work, the rate this chip sustains at its loaded clock.
+            static const int wide_env = getenv("ACAI_ATTN64_BWD_WIDE") ? atoi(getenv("ACAI_ATTN64_BWD_WIDE")) : -1;
             if (wide_env && !a.causal && a.dh == 64) {
-                const bool wq = (wide_env & 1) && max_q >= 256, wk = (wide_env & 2) && max_k >= 256 && !a.accum_dkv;
+                const bool wq = (wide_env & 1) && max_q >= 256, wk = (wide_env & 2) && max_k >= 256 && !a.accum_dkv && (wide_env > 0 || max_q >= 2048);
                 // when every sequence is max_q long (B * max_q rows in all) the host knows whether a tail exists; keys: only for self-attention
                 const bool eq_q = (long long)B * max_q == (long long)a.total_q, eq_k = eq_q && a.cu_k == a.cu_q && max_k == max_q;
                 BwdArgs t = a;

@@ -23,6 +23,9 @@
 // tile and a half ahead through a three-slot ring (tile t+2's loads are issued in tile t's first block, written to the slot tile t-1 left
 // in its second block), one barrier per tile.  The accumulator start values carry the row constants as in attn_bwd.hip: S starts at -lse,
 // dP at -delta, so P = 2^S' and dS = P dP' are one exp2 + one multiply per score.
+// Register halves: the dK / dV kernel needs 128 (gradients) + 64 (K / V fragments) + 32 (transposed fragments) accumulator-half registers and ~210
+// architectural ones; left to the allocator the K / V fragments ended up partly architectural and the kernel spilt to scratch (2894 us against the
+// one-block kernel's 2142 on 16 x 16 x 4096^2) - its S / dP MFMAs are therefore inline asm with the B operand constrained to "a" (1886 us, no spill).
 #include "attn_bwd_args.h"
 
 #include <type_traits>
@@ -72,6 +75,26 @@ __device__ __forceinline__ void mma_acc(f32x16 &c, const uint4 &a, const uint4 &
 }
 __device__ __forceinline__ f32x16 mma(const uint4 &af, const uint4 &bf, const f32x16 &c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), c, 0, 0, 0);
+}
+// S / dP chains of the dK / dV kernel: D and C architectural (the VALU reads them two MFMA gaps later at the earliest), the B operand - a K / V fragment of
+// an owned block, live for the whole kernel - PINNED to the accumulator half: left to the allocator, part of those 64 registers stayed architectural
+// and the kernel spilt to scratch (ACAI_BWD64W_DKV_ASM=0: the builtin form, A/B aid).
+#ifndef ACAI_BWD64W_DKV_ASM
+#define ACAI_BWD64W_DKV_ASM 1
+#endif
+__device__ __forceinline__ void mma_ab0(f32x16 &d, const uint4 &a, const uint4 &b, const f32x16 &c) {   // d = A . B + c
+    if constexpr (ACAI_BWD64W_DKV_ASM) {
+        const u32x4 av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(av), "a"(bv), "v"(c));   // (no s_nop: operands come from LDS reads, AGPR constants and MFMAs; _asmcheck verifies)
+    } else
+        d = mma(a, b, c);
+}
+__device__ __forceinline__ void mma_ab(f32x16 &d, const uint4 &a, const uint4 &b) {   // d += A . B
+    if constexpr (ACAI_BWD64W_DKV_ASM) {
+        const u32x4 av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(av), "a"(bv));
+    } else
+        d = mma(a, b, d);
 }
 
 // ---- the VALU stream of one (owned block, streamed block) pair, as numbered single-issue operations -------------------------------------------
@@ -510,7 +533,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // g0-7: S0, dP0 of block b | P1, dS1 of block b-1: operations 24..47
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            if constexpr (BODY) sc[0] = mma(qr[s], kf[0][s], s == 0 ? nl : sc[0]);
+            if constexpr (BODY) {
+                if (s == 0) mma_ab0(sc[0], qr[s], kf[0][s], nl);
+                else mma_ab(sc[0], qr[s], kf[0][s]);
+            }
             if constexpr (!FIRST) {
                 if (s == 0) dkv_ops<24, 27, MP>(sc[1], dp[1], xp[1], xs[1], row0 - 32, lh, lq, true);
                 if (s == 1) dkv_ops<30, 33, MP>(sc[1], dp[1], xp[1], xs[1], row0 - 32, lh, lq, true);
@@ -518,7 +544,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 if (s == 3) dkv_ops<42, 45, MP>(sc[1], dp[1], xp[1], xs[1], row0 - 32, lh, lq, true);
             }
             ACAI_SB();
-            if constexpr (BODY) dp[0] = mma(dor[s], vf[0][s], s == 0 ? nd : dp[0]);
+            if constexpr (BODY) {
+                if (s == 0) mma_ab0(dp[0], dor[s], vf[0][s], nd);
+                else mma_ab(dp[0], dor[s], vf[0][s]);
+            }
             if constexpr (!FIRST) {
                 if (s == 0) dkv_ops<27, 30, MP>(sc[1], dp[1], xp[1], xs[1], row0 - 32, lh, lq, true);
                 if (s == 1) dkv_ops<33, 36, MP>(sc[1], dp[1], xp[1], xs[1], row0 - 32, lh, lq, true);
@@ -558,14 +587,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             // g16-23: S1, dP1 of block b | P0, dS0 of block b: operations 24..47 | row fragments of block b + 1 behind their last use
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                sc[1] = mma(qr[s], kf[1][s], s == 0 ? nl : sc[1]);
+                if (s == 0) mma_ab0(sc[1], qr[s], kf[1][s], nl);
+                else mma_ab(sc[1], qr[s], kf[1][s]);
                 if (s == 0) dkv_ops<24, 27, MC>(sc[0], dp[0], xp[0], xs[0], row0, lh, lq, true);
                 if (s == 1) dkv_ops<30, 33, MC>(sc[0], dp[0], xp[0], xs[0], row0, lh, lq, true);
                 if (s == 2) dkv_ops<36, 39, MC>(sc[0], dp[0], xp[0], xs[0], row0, lh, lq, true);
                 if (s == 3) dkv_ops<42, 45, MC>(sc[0], dp[0], xp[0], xs[0], row0, lh, lq, true);
                 qr[s] = read_r(next, s);
                 ACAI_SB();
-                dp[1] = mma(dor[s], vf[1][s], s == 0 ? nd : dp[1]);
+                if (s == 0) mma_ab0(dp[1], dor[s], vf[1][s], nd);
+                else mma_ab(dp[1], dor[s], vf[1][s]);
                 if (s == 0) dkv_ops<27, 30, MC>(sc[0], dp[0], xp[0], xs[0], row0, lh, lq, true);
                 if (s == 1) dkv_ops<33, 36, MC>(sc[0], dp[0], xp[0], xs[0], row0, lh, lq, true);
                 if (s == 2) dkv_ops<39, 42, MC>(sc[0], dp[0], xp[0], xs[0], row0, lh, lq, true);
