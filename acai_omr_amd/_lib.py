@@ -7,11 +7,11 @@ without a GPU); the built .so is git-ignored but travels to the GPU box with the
 import ctypes
 import os
 import subprocess
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p, c_size_t
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("ACAI_OMR_LIB") or os.path.join(CSRC, "libacai_omr_hip.so")   # (override: A/B builds of the same sources, tools/ab_*.sh)
-SOURCES = ["gemm.hip", "elementwise.hip", "attn_varlen.hip", "attn_fwd64.hip", "attn_fwd64w.hip", "attn_bwd.hip", "attn_bwd64w.hip", "train.hip", "decode.hip", "resize.hip"]
+SOURCES = ["gemm.hip", "elementwise.hip", "attn_varlen.hip", "attn_fwd64.hip", "attn_fwd64w.hip", "attn_bwd.hip", "attn_bwd64w.hip", "attn_bwd1p.hip", "train.hip", "decode.hip", "resize.hip"]
 
 ACAI_F32, ACAI_BF16 = 0, 1
 GEMM_GELU, GEMM_ROUND_BF16 = 1, 2
@@ -69,6 +69,10 @@ _SIGNATURES = {
     "acai_attn_varlen_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                                      c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_int, c_int, c_float, c_uint32, c_int, c_void_p]),
+    "acai_attn_varlen_bwd_ws": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                        c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                        c_int, c_int, c_int, c_int, c_float, c_uint32, c_int, c_void_p, c_size_t, c_void_p]),
+    "acai_attn_varlen_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int]),
     "acai_dropout_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_uint32, c_int, c_int, c_void_p]),
     "acai_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "acai_gelu_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
@@ -119,7 +123,8 @@ def build(force=False, verbose=False):
     per_file = {"attn_varlen.hip": ["-fno-slp-vectorize"], "attn_fwd64.hip": ["-fno-slp-vectorize"],
                 # (one wave per SIMD: the score MFMAs must write VGPRs, the output accumulators are asm-owned AGPRs - see the file header)
                 "attn_fwd64w.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"], "attn_bwd.hip": ["-fno-slp-vectorize"],
-                "attn_bwd64w.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]}
+                "attn_bwd64w.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"],
+                "attn_bwd1p.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]}
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
 
@@ -129,7 +134,7 @@ def build(force=False, verbose=False):
     # Sources whose correctness rests on something the compiler does not model (asm loads it cannot see, a counted LDS wait): their generated
     # assembly is checked on every rebuild and a hit FAILS the build (acai_omr_amd/_asmcheck.py; ADVICE r3: the check used to be a manual tool).
     asm_checks = {"gemm.hip": ["check_untracked_loads"], "attn_fwd64w.hip": ["check_fwd64w_barrier", "check_asm_mfma_operands"],
-                  "attn_bwd64w.hip": ["check_asm_mfma_operands"]}
+                  "attn_bwd64w.hip": ["check_asm_mfma_operands"], "attn_bwd1p.hip": ["check_asm_mfma_operands"]}
     jobs, to_check = [], []
     for src in srcs:
         base = os.path.basename(src)

@@ -928,8 +928,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     }
 }
 
+// the shapes the one-pass kernel takes (beyond bf16 / prescaled / no dropout / aligned operands, which the dispatch checks by its template arguments)
+inline bool bwd1p_shape_ok(int dh, int causal, int accum, int B, int max_q, int max_k, int total_k) {
+    return dh == 32 && !causal && !accum && max_k >= 512 && max_k % 512 == 0 && max_q >= 512 && total_k > 0 && (long long)B * max_k == (long long)total_k;
+}
+
 template <typename T, int DHP>
-int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, bool pre, hipStream_t st) {
+int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, bool pre, void *ws, size_t ws_bytes, int total_k, hipStream_t st) {
     constexpr int ES = sizeof(T), EPC = 16 / ES;
     const bool fast = (a.dh % EPC == 0) && (a.ldq % EPC == 0) && (a.ldk % EPC == 0) && (a.ldv % EPC == 0) && (a.lddo % EPC == 0) && (a.ldo % EPC == 0) &&
                       aligned16(a.q) && aligned16(a.k) && aligned16(a.v) && aligned16(a.dout) && aligned16(a.o) &&
@@ -954,6 +959,14 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, bool pre, hipStrea
             if (acai_first_on_device(attr2)) {
                 hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
                 hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            }
+            // one pass over the scores (attn_bwd1p.hip) when the caller lent a workspace and the shape allows: every sequence max_k keys, a
+            // multiple of 512 (ACAI_ATTN_BWD_1P=0: keep the two kernels below, whose dQ is bit-reproducible - the one-pass form adds the key
+            // blocks' contributions to a query's gradient in arrival order)
+            static const int onepass_env = getenv("ACAI_ATTN_BWD_1P") ? atoi(getenv("ACAI_ATTN_BWD_1P")) : 1;
+            if (onepass_env && bwd1p_shape_ok(a.dh, a.causal, a.accum_dkv, B, max_q, max_k, total_k) && ws && ws_bytes >= acai_attn_bwd1p_workspace(a.total_q, a.H)) {
+                acai_attn_bwd1p_launch(a, B, max_k, ws, st);
+                return;
             }
             if (nq_env == 2 && !a.causal && !a.accum_dkv && max_q >= 512 && max_k >= 512) {
                 hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(cdiv(max_q, 2 * OB), a.H, B), dim3(256), lds_dq, st, a);
@@ -1012,13 +1025,15 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, bool pre, hipStrea
 
 }  // namespace
 
-extern "C" int acai_attn_varlen_bwd(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, const void *o, int ldo,
-                                    const void *dout, int lddo, void *dq, int lddq, void *dk, int lddk, void *dv, int lddv, const float *lse,
-                                    float *delta, const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int max_k,
-                                    int total_q, int causal, int dtype, float dropout_p, uint32_t dropout_seed, int q_prescaled, void *stream) {
+extern "C" int acai_attn_varlen_bwd_ws(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, const void *o, int ldo,
+                                       const void *dout, int lddo, void *dq, int lddq, void *dk, int lddk, void *dv, int lddv, const float *lse,
+                                       float *delta, const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int max_k,
+                                       int total_q, int total_k, int causal, int dtype, float dropout_p, uint32_t dropout_seed, int q_prescaled,
+                                       void *workspace, size_t workspace_bytes, void *stream) {
     ACAI_CHECK_ARG(q && k && v && o && dout && dq && dk && dv && lse && delta && cu_q && cu_k, "acai_attn_varlen_bwd: null operand");
     ACAI_CHECK_ARG(B > 0 && H > 0 && dh > 0 && dh <= 64 && max_q > 0 && max_k > 0 && total_q > 0 && B <= 65535 && H <= 65535,
                    "acai_attn_varlen_bwd: bad dims");
+    ACAI_CHECK_ARG(total_k >= 0 && (workspace || !workspace_bytes), "acai_attn_varlen_bwd_ws: bad workspace / total_k");
     BwdArgs a{};
     a.q = q; a.k = k; a.v = v; a.o = o; a.dout = dout; a.dq = dq; a.dk = dk; a.dv = dv; a.lse = lse; a.delta = delta; a.cu_q = cu_q; a.cu_k = cu_k;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
@@ -1030,7 +1045,25 @@ extern "C" int acai_attn_varlen_bwd(const void *q, int ldq, const void *k, int l
     a.scale_log2e = 1.4426950408889634f * a.scale;
     hipStream_t st = (hipStream_t)stream;
     const bool pre = q_prescaled != 0;
-    if (dtype == ACAI_BF16) return dh <= 32 ? launch_bwd<bf16_t, 32>(a, B, max_q, max_k, pre, st) : launch_bwd<bf16_t, 64>(a, B, max_q, max_k, pre, st);
-    if (dtype == ACAI_F32) return dh <= 32 ? launch_bwd<float, 32>(a, B, max_q, max_k, pre, st) : launch_bwd<float, 64>(a, B, max_q, max_k, pre, st);
+    if (dtype == ACAI_BF16)
+        return dh <= 32 ? launch_bwd<bf16_t, 32>(a, B, max_q, max_k, pre, workspace, workspace_bytes, total_k, st)
+                        : launch_bwd<bf16_t, 64>(a, B, max_q, max_k, pre, nullptr, 0, total_k, st);
+    if (dtype == ACAI_F32)
+        return dh <= 32 ? launch_bwd<float, 32>(a, B, max_q, max_k, pre, nullptr, 0, total_k, st) : launch_bwd<float, 64>(a, B, max_q, max_k, pre, nullptr, 0, total_k, st);
     return acai_set_err(-1, "acai_attn_varlen_bwd: bad dtype %d", dtype);
+}
+
+extern "C" size_t acai_attn_varlen_bwd_workspace_bytes(int B, int H, int dh, int max_q, int max_k, int total_q, int total_k, int causal, int dtype,
+                                                       float dropout_p, int q_prescaled) {
+    if (dtype != ACAI_BF16 || !q_prescaled || dropout_p != 0.f || B <= 0 || H <= 0 || total_q <= 0) return 0;
+    if (getenv("ACAI_ATTN_BWD_1P") && atoi(getenv("ACAI_ATTN_BWD_1P")) == 0) return 0;
+    return bwd1p_shape_ok(dh, causal & 1, (causal >> 1) & 1, B, max_q, max_k, total_k) ? acai_attn_bwd1p_workspace(total_q, H) : 0;
+}
+
+extern "C" int acai_attn_varlen_bwd(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, const void *o, int ldo,
+                                    const void *dout, int lddo, void *dq, int lddq, void *dk, int lddk, void *dv, int lddv, const float *lse,
+                                    float *delta, const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int max_k,
+                                    int total_q, int causal, int dtype, float dropout_p, uint32_t dropout_seed, int q_prescaled, void *stream) {
+    return acai_attn_varlen_bwd_ws(q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, dq, lddq, dk, lddk, dv, lddv, lse, delta, cu_q, cu_k, B, H, dh, max_q, max_k,
+                                   total_q, 0, causal, dtype, dropout_p, dropout_seed, q_prescaled, nullptr, 0, stream);
 }

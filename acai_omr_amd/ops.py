@@ -346,6 +346,17 @@ def decode_attn(q, kc, vc, seq_off, seq_len, H, dh, dhp, max_len, round_out=Fals
     return out
 
 
+_BWD_WS = {}   # (device, stream) -> the one-pass attention backward's fp32 query-gradient workspace (used only inside a call, in stream order)
+
+
+def _bwd_workspace(device, nbytes):
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _BWD_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _BWD_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return ws
+
+
 def attn_varlen_bwd(q, k, v, o, dout, lse, cu_q, cu_k, H, dh, max_q, max_k, causal, dq, dk, dv, dropout_p=0.0, seed=0, q_prescaled=False, accumulate_dkv=False):
     """Gradients of attn_varlen w.r.t. q, k, v, written into the (strided) views dq, dk, dv.  q_prescaled: q is the forward's prescaled
     q; dq is still the gradient w.r.t. the unscaled in-projection output.  accumulate_dkv: dk, dv += (bf16, aligned operands only)."""
@@ -357,12 +368,16 @@ def attn_varlen_bwd(q, k, v, o, dout, lse, cu_q, cu_k, H, dh, max_q, max_k, caus
     total_q = q.shape[0]
     assert lse.numel() == H * total_q and dout.shape == o.shape
     delta = torch.empty(H * total_q, dtype=torch.float32, device=q.device)
-    _lib.check(_lib.lib().acai_attn_varlen_bwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), o.data_ptr(), o.stride(0),
-                                               dout.data_ptr(), dout.stride(0), dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(),
-                                               dv.stride(0), lse.data_ptr(), delta.data_ptr(), cu_q.data_ptr(), cu_k.data_ptr(), B, H, dh, int(max_q),
-                                               int(max_k), total_q, (1 if causal else 0) | (2 if accumulate_dkv else 0), _dt(q), float(dropout_p), int(seed) & 0xFFFFFFFF,
-                                               1 if q_prescaled else 0, _st()),
-               "acai_attn_varlen_bwd")
+    flags = (1 if causal else 0) | (2 if accumulate_dkv else 0)
+    total_k = k.shape[0]
+    need = _lib.lib().acai_attn_varlen_bwd_workspace_bytes(B, H, dh, int(max_q), int(max_k), total_q, total_k, flags, _dt(q), float(dropout_p), 1 if q_prescaled else 0)
+    ws = _bwd_workspace(q.device, need) if need else None
+    _lib.check(_lib.lib().acai_attn_varlen_bwd_ws(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), o.data_ptr(), o.stride(0),
+                                                  dout.data_ptr(), dout.stride(0), dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(),
+                                                  dv.stride(0), lse.data_ptr(), delta.data_ptr(), cu_q.data_ptr(), cu_k.data_ptr(), B, H, dh, int(max_q),
+                                                  int(max_k), total_q, total_k, flags, _dt(q), float(dropout_p), int(seed) & 0xFFFFFFFF,
+                                                  1 if q_prescaled else 0, _p(ws), need if ws is not None else 0, _st()),
+               "acai_attn_varlen_bwd_ws")
 
 
 def dropout_add(x, residual, p, seed, out_dtype=None):

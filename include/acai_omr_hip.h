@@ -149,6 +149,19 @@ int acai_attn_varlen_bwd(const void *q, int ldq, const void *k, int ldk, const v
                          const void *dout, int lddo, void *dq, int lddq, void *dk, int lddk, void *dv, int lddv, const float *lse,
                          float *delta, const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int max_k,
                          int total_q, int causal, int dtype, float dropout_p, uint32_t dropout_seed, int q_prescaled, void *stream);
+/* The same backward with a caller-lent device workspace (round 4).  With bf16, d_h = 32, q_prescaled, no dropout / mask / accumulation and every
+ * sequence exactly max_k keys long (total_k = B * max_k, the rows of k / v; max_k % 512 == 0, max_q >= 512) - the MAE decoder's self-attention
+ * (models.py:186-190) - dQ, dK and dV come from ONE pass over the scores (attn_bwd1p.hip): the key blocks add their part of a query's gradient
+ * to the fp32 workspace with float atomics, so dQ is reproducible to fp32 rounding, not bit for bit (ACAI_ATTN_BWD_1P=0 in the environment, or
+ * no workspace, keeps the two-kernel form, which is).  acai_attn_varlen_bwd_workspace_bytes: bytes that form needs for a call with these
+ * arguments, 0 when it does not apply (then any workspace is ignored).  The workspace is used only inside the call (stream order). */
+size_t acai_attn_varlen_bwd_workspace_bytes(int B, int H, int dh, int max_q, int max_k, int total_q, int total_k, int causal, int dtype,
+                                            float dropout_p, int q_prescaled);
+int acai_attn_varlen_bwd_ws(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, const void *o, int ldo,
+                            const void *dout, int lddo, void *dq, int lddq, void *dk, int lddk, void *dv, int lddv, const float *lse,
+                            float *delta, const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int max_k,
+                            int total_q, int total_k, int causal, int dtype, float dropout_p, uint32_t dropout_seed, int q_prescaled,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* Backward of nn.LayerNorm: dx (fp32) from x, w, dy; dw/db (both or neither NULL) are ACCUMULATED with fp32 atomics (zero or seed
  * them); dx_bf16 (may be NULL; needs dim % 256 == 0, dim <= 1024): bf16 copy of dx for the GEMM that consumes it; dxsum (may be NULL, same
