@@ -210,6 +210,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         return f;
     };
 
+    // The dS images have their own chunk swizzle, f(row) = ((row >> 1) ^ ((row >> 3) & 1)) & 3 (the same for rows 16 apart): the 16-byte writes of a pack (lane = row lr, one chunk
+    // column) collide pairwise under the tiles' (row >> 2) & 3 - measured 64 against 52 cycles an instruction with four waves writing
+    // (tools/experiments/lds_patterns.hip), SQ_LDS_BANK_CONFLICT 783 cycles a tile - while the transposing reads only need aligned chunk pairs to
+    // stay pairs, which any XOR swizzle keeps.
+    auto ds_off = [&](int row, int chunk) -> int { return row * PITCH + ((chunk ^ (((row >> 1) ^ ((row >> 3) & 1)) & 3)) << 4); };
+    int dsw[2], dst_addr[2];
+#pragma unroll
+    for (int P = 0; P < 2; ++P) dsw[P] = ds_off(lr, 2 * P + lh);
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) dst_addr[r2] = ds_off(4 * lh + (i16 >> 2) + 8 * r2, 2 * g1 + ((i16 & 3) >> 1)) + 8 * (i16 & 1);
+    auto read_td = [&](const unsigned char *img, int s2) -> TF {
+        TF f;
+        f.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(img + s2 * 16 * PITCH + dst_addr[0]));
+        f.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(img + s2 * 16 * PITCH + dst_addr[1]));
+        return f;
+    };
+
     // ---- lane-owned keys: K / V fragments (B operands of S = Q K^T, dP = dO V^T) --------------------------------------------------------------------
     u32x4 kf[4][2], vf[4][2];
     unsigned char *kimg = lds + LDS_P + wave * (KBW * PITCH);   // the wave's 128 K rows, natural image, for the prologue only (partial-tile set 0 later)
@@ -283,25 +300,36 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // waves' tiles are summed and added to the fp32 gradient with no-return float atomics, lanes along d: one instruction adds two 128-byte row
     // segments.  Three buffer sets by tile % 3: tile t's tiles are complete at tile t+1's closing barrier (the second query block's flush is in tile
     // t+1's second slot), are added during tile t+2's first slot, and are overwritten from tile t+3 on - one barrier per tile serves the ring and this.
-    const int pflush_v = wave * PTILE + (lr * PROW + 4 * lh) * 4;       // flush: lane = query lr, registers 4 g4 + i = d 8 g4 + 4 lh + i
-    const int pred_v = ((2 * wave + lh) * PROW + lr) * 4;               // sum: lane = d lr of query row 2 wave + lh (+ 8 k)
-    const int row8 = 8 * ldq32 * 4;                                     // bytes between gradient rows q and q + 8
-    const uint32_t avoff = (uint32_t)(((2 * wave + lh) * ldq32 + lr) * 4);
+    const int qcol = (lr & 19) | ((lr & 4) << 1) | ((lr & 8) >> 1);     // the query behind column lr of the dS image (bits 2 and 3 swapped)
+    const int pflush_v = wave * PTILE + (qcol * PROW + 4 * lh) * 4;     // flush: lane = query qcol, registers 4 g4 + i = d 8 g4 + 4 lh + i
+    // sum: lane = d lr of query rows wave + 8 lh (+ 4 (k & 1) + 16 (k >> 1)): the two half-waves read rows 8 apart = 32 banks apart (PROW = 36)
+    const int pred_v = ((wave + 8 * lh) * PROW + lr) * 4;
+    const int row4 = 4 * ldq32 * 4;                                     // bytes between gradient rows q and q + 4
+    const uint32_t avoff = (uint32_t)(((wave + 8 * lh) * ldq32 + lr) * 4);
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(DQ32, 0, lq > 0 ? ((lq - 1) * ldq32 + 32) * 4 : 0, 0x00020000);
-    auto flush_tile = [&](int pset_qb) {   // (the last dQ MFMA of the block is at least five MFMAs back)
-        unsigned char *pt = lds + pset_qb + pflush_v;
+    float ra[8][4];   // partial-tile elements between their LDS read and their add (a few gaps: the register allocator sees short live ranges)
+    auto flush_piece = [&](int pset_qb, int g4) {   // (constant g4 at every call)
+        unsigned char *pt = lds + pset_qb + pflush_v + 32 * g4;
+        switch (g4) {
+            case 0: *reinterpret_cast<f32x4 *>(pt) = f32x4{dqa[0], dqa[1], dqa[2], dqa[3]}; break;
+            case 1: *reinterpret_cast<f32x4 *>(pt) = f32x4{dqa[4], dqa[5], dqa[6], dqa[7]}; break;
+            case 2: *reinterpret_cast<f32x4 *>(pt) = f32x4{dqa[8], dqa[9], dqa[10], dqa[11]}; break;
+            default: *reinterpret_cast<f32x4 *>(pt) = f32x4{dqa[12], dqa[13], dqa[14], dqa[15]}; break;
+        }
+    };
+    auto flush_tile = [&](int pset_qb) {
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4)
-            *reinterpret_cast<f32x4 *>(pt + 32 * g4) = f32x4{dqa[4 * g4], dqa[4 * g4 + 1], dqa[4 * g4 + 2], dqa[4 * g4 + 3]};
+        for (int g4 = 0; g4 < 4; ++g4) flush_piece(pset_qb, g4);
     };
     auto reduce_plain = [&](int t, int pset) {   // outside the steady state: rows past the sequence's end are dropped by the buffer's range check
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
-            const unsigned char *pp = lds + pset + pred_v + (n >> 2) * 4 * PTILE + (n & 3) * 8 * PROW * 4;
+            const int rown = 4 * (n & 1) + 16 * ((n >> 1) & 1);
+            const unsigned char *pp = lds + pset + pred_v + (n >> 2) * 4 * PTILE + rown * PROW * 4;
             float sum = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) sum += *reinterpret_cast<const float *>(pp + w * PTILE);
-            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(sum, rA, avoff + (uint32_t)((t * QT + (n >> 2) * 32 + (n & 3) * 8) * ldq32 * 4), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(sum, rA, avoff + (uint32_t)((t * QT + (n >> 2) * 32 + rown) * ldq32 * 4), 0, 0);
         }
     };
 
@@ -312,11 +340,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     //   FLUSH: the finished partial dQ^T tile goes to LDS (offset pflush: set and query block) in front of gap 7, where item w-1 - the first owned
     //   block of the NEXT query block - starts the accumulator afresh
     //   REDUCE: the eight elements per thread of the partial tiles in set pred are summed and added to the gradient rows at byte offset arow: element n
-    //   is read in gap n and added in gap n + 2
+    //   is read in gap n of the tile's first slot and added four gaps later (the last two in the second slot's first gaps)
     auto slot = [&](auto hasE_, auto hasA_, auto hasC_, auto mask_, auto loadrow_, auto loadt_, auto flush_, auto reduce_, auto pE_, auto jA_, auto jC_,
                     int rowE, int nextrow, int nextstat, int tblk, int pflush, int pred, int arow) __attribute__((always_inline)) {
         constexpr bool HE = decltype(hasE_)::value, HA = decltype(hasA_)::value, HC = decltype(hasC_)::value, M = decltype(mask_)::value;
-        constexpr bool LOADROW = decltype(loadrow_)::value, LOADT = decltype(loadt_)::value, FLUSH = decltype(flush_)::value, REDUCE = decltype(reduce_)::value;
+        constexpr bool LOADROW = decltype(loadrow_)::value, LOADT = decltype(loadt_)::value, FLUSH = decltype(flush_)::value;
+        constexpr int REDUCE = decltype(reduce_)::value;
         constexpr int pE = decltype(pE_)::value, jA = decltype(jA_)::value, jC = decltype(jC_)::value;
         constexpr bool NP = M || !HE || !HA || !HC;   // outside the steady-state loop the compiler's tuple copies at region edges may sit in front of an MFMA: pad
         f32x16 &sE = sc[pE], &pEd = dp[pE], &sA = sc[pE ^ 1], &pA = dp[pE ^ 1];
@@ -324,34 +353,34 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         unsigned char *dsimg = dsreg + (pE ^ 1) * (32 * PITCH);
         const unsigned char *rowp = lds + nextrow, *tp = lds + tblk;
         TF dst[2];   // dS^T fragments of item w-1
-        float ra[3][4];
-        auto red = [&](auto g_) __attribute__((always_inline)) {
+        auto red = [&](auto g_) __attribute__((always_inline)) {   // REDUCE: 1 = the tile's first slot, 2 = its second (the last two elements' adds)
             constexpr int g = decltype(g_)::value;
-            if constexpr (REDUCE && g < 8) {
-                const unsigned char *pp = lds + pred + pred_v + (g >> 2) * 4 * PTILE + (g & 3) * 8 * PROW * 4;
+            if constexpr (REDUCE == 1 && g < 8) {
+                const unsigned char *pp = lds + pred + pred_v + (g >> 2) * 4 * PTILE + (4 * (g & 1) + 16 * ((g >> 1) & 1)) * PROW * 4;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) ra[g % 3][w] = *reinterpret_cast<const float *>(pp + w * PTILE);
+                for (int w = 0; w < 4; ++w) ra[g][w] = *reinterpret_cast<const float *>(pp + w * PTILE);
             }
-            if constexpr (REDUCE && g >= 2) {
-                constexpr int n = g - 2;
-                const float sum = (ra[n % 3][0] + ra[n % 3][1]) + (ra[n % 3][2] + ra[n % 3][3]);
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(sum, rA, avoff, arow + (4 * (n >> 2) + (n & 3)) * row8, 0);
+            constexpr int n = REDUCE == 1 ? g - 4 : g + 6;
+            if constexpr ((REDUCE == 1 && g >= 4) || (REDUCE == 2 && g < 2)) {
+                const float sum = (ra[n][0] + ra[n][1]) + (ra[n][2] + ra[n][3]);
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(sum, rA, avoff, arow + (8 * (n >> 2) + (n & 1) + 4 * ((n >> 1) & 1)) * row4, 0);
             }
         };
-        // gap 0: A, S k-step 0 | the dS image of item w-1 -> LDS (lane = key: its 32 q values as four 8-byte pieces)
+        // gap 0: A, S k-step 0 | the second half of the dS image of item w-1 -> LDS (the first went out in its own E phase, gap 6: LDS writes move
+        // ~36 bytes a clock per wave, two in a row stall the wave's next LDS instruction).  Lane = key: its 32 q values as the two 16-byte packs the
+        // dK product reads - q in the order 16 P + 8 gl + 4 lh + i at column 16 P + 8 lh + 4 gl + i (bits 2 and 3 swapped), which the flush undoes
         if constexpr (HA) mma_ab0<NP>(sA, qr[0], kf[jA][0], nl);
+        ACAI_SB();
         if constexpr (HE) e_gap<0, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
-        if constexpr (HC) {
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) *reinterpret_cast<u32x2 *>(dsimg + TL::off(lr, g4) + 8 * lh) = u32x2{xsC[2 * g4], xsC[2 * g4 + 1]};
-        }
+        if constexpr (HC) *reinterpret_cast<uint4 *>(dsimg + dsw[1]) = x4(xsC, 1);
         if constexpr (LOADROW) qr[0] = read_r(rowp, 0);
         red(I<0>{});
         ACAI_SB();
         // gap 1: C, dV k-step 0
         if constexpr (HC) mma_acc<NP>(dv[jC], dot[0].u, x4(xpC, 0));
+        ACAI_SB();
         if constexpr (HE) e_gap<1, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
-        if constexpr (HC) dst[0] = read_t(dsimg, 0);
+        if constexpr (HC) dst[0] = read_td(dsimg, 0);
         if constexpr (LOADROW) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) read_init(nl, nextstat, g4);
@@ -361,40 +390,46 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         ACAI_SB();
         // gap 2: A, dP k-step 0
         if constexpr (HA) mma_ab0<NP>(pA, dor[0], vf[jA][0], nd);
+        ACAI_SB();
         if constexpr (HE) e_gap<2, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
-        if constexpr (HC) dst[1] = read_t(dsimg, 1);
+        if constexpr (HC) dst[1] = read_td(dsimg, 1);
         if constexpr (LOADROW) dor[0] = read_r(rowp + TILE, 0);
+        if constexpr (FLUSH) flush_piece(pflush, 0);   // (the block's last dQ MFMA is three MFMAs back; the next one that writes dqa is gap 7's)
         red(I<2>{});
         ACAI_SB();
         // gap 3: C, dV k-step 1
         if constexpr (HC) mma_acc<NP>(dv[jC], dot[1].u, x4(xpC, 1));
+        ACAI_SB();
         if constexpr (HE) e_gap<3, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
         if constexpr (LOADROW) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) read_init(nd, nextstat + QT * 4, g4);
         }
         if constexpr (LOADT) dot[1] = read_t(tp + TILE, 1);
+        if constexpr (FLUSH) flush_piece(pflush, 1);
         red(I<3>{});
         ACAI_SB();
         // gap 4: A, S k-step 1
         if constexpr (HA) mma_ab<NP>(sA, qr[1], kf[jA][1]);
+        ACAI_SB();
         if constexpr (HE) e_gap<4, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
         if constexpr (LOADROW) qr[1] = read_r(rowp, 1);
+        if constexpr (FLUSH) flush_piece(pflush, 2);
         red(I<4>{});
         ACAI_SB();
-        if constexpr (FLUSH) {
-            flush_tile(pflush);
-            ACAI_SB();
-        }
         // gap 5: C, dK k-step 0
         if constexpr (HC) mma_acc<NP>(dk[jC], qt[0].u, x4(xsC, 0));
+        ACAI_SB();
         if constexpr (HE) e_gap<5, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
         if constexpr (LOADT) qt[0] = read_t(tp, 0);
+        if constexpr (FLUSH) flush_piece(pflush, 3);
         red(I<5>{});
         ACAI_SB();
         // gap 6: A, dP k-step 1
         if constexpr (HA) mma_ab<NP>(pA, dor[1], vf[jA][1]);
+        ACAI_SB();
         if constexpr (HE) e_gap<6, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
+        if constexpr (HE) *reinterpret_cast<uint4 *>(dsreg + pE * (32 * PITCH) + dsw[0]) = x4(xsE, 0);   // (its last pair was packed in gap 5)
         if constexpr (LOADROW) dor[1] = read_r(rowp + TILE, 1);
         red(I<6>{});
         ACAI_SB();
@@ -403,17 +438,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             if constexpr (jC == 0) mma_acca0<NP>(dqa, ktf[jC][0], dst[0].u);
             else mma_acca<NP>(dqa, ktf[jC][0], dst[0].u);
         }
+        ACAI_SB();
         if constexpr (HE) e_gap<7, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
         red(I<7>{});
         ACAI_SB();
         // gap 8: C, dK k-step 1 (between the two dQ k-steps: a dependent MFMA directly behind its producer waits for the whole pass)
         if constexpr (HC) mma_acc<NP>(dk[jC], qt[1].u, x4(xsC, 1));
+        ACAI_SB();
         if constexpr (HE) e_gap<8, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
         if constexpr (LOADT) qt[1] = read_t(tp, 1);
         red(I<8>{});
         ACAI_SB();
         // gap 9: C, dQ k-step 1
         if constexpr (HC) mma_acca<NP>(dqa, ktf[jC][1], dst[1].u);
+        ACAI_SB();
         if constexpr (HE) e_gap<9, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
         red(I<9>{});
         ACAI_SB();
@@ -446,7 +484,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // item -1: only A(item 0).  Its "gradient products" in the first real slot multiply ZERO packs, and the partial tile it "finishes" is zero
 #pragma unroll
         for (int n = 0; n < 8; ++n) xp[1][n] = xs[1][n] = 0u;
-        slot(N{}, Y{}, N{}, N{}, N{}, N{}, N{}, N{}, I<1>{}, I<0>{}, I<0>{}, 0, 0, 0, 0, 0, 0, 0);
+        *reinterpret_cast<uint4 *>(dsreg + 32 * PITCH + dsw[0]) = make_uint4(0u, 0u, 0u, 0u);   // (the half of item -1's dS image its E phase would have written)
+        slot(N{}, Y{}, N{}, N{}, N{}, N{}, N{}, I<0>{}, I<1>{}, I<0>{}, I<0>{}, 0, 0, 0, 0, 0, 0, 0);
 
         // One tile = 8 items (query blocks qb = 0, 1 x owned blocks j = 0..3).  Slot of item (qb, j): E(qb, j) | A(next item) | C(previous item).
         //   (0, 0): the partial tiles of tile t-2 are added to the gradient
@@ -456,17 +495,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         int o0 = 0, o1 = QSLOT, o2 = 2 * QSLOT;                              // ring slots of tiles t, t+1, t+2
         int p0 = LDS_P, p1 = LDS_P + PSET, p2 = LDS_P + 2 * PSET;            // partial-tile sets of tiles t, t+1 (= t-2), t+2 (= t-1)
         auto tile = [&](auto mask_, int t) __attribute__((always_inline)) {
-            const int r0 = t * QT, arow = (t >= 2 ? t - 2 : 0) * (QT / 8) * row8;
+            const int r0 = t * QT, arow = (t >= 2 ? t - 2 : 0) * (QT / 4) * row4;
             load_tile(t + 2);
-            slot(Y{}, Y{}, Y{}, mask_, N{}, Y{}, N{}, Y{}, I<0>{}, I<1>{}, I<3>{}, r0, 0, 0, o0, 0, p1, arow);                                       // (0, 0)
-            slot(Y{}, Y{}, Y{}, mask_, N{}, N{}, Y{}, N{}, I<1>{}, I<2>{}, I<0>{}, r0, 0, 0, 0, p2 + 4 * PTILE, 0, 0);                               // (0, 1)
-            slot(Y{}, Y{}, Y{}, mask_, Y{}, N{}, N{}, N{}, I<0>{}, I<3>{}, I<1>{}, r0, o0 + 32 * PITCH, o0 + 2 * TILE + 32 * 4, 0, 0, 0, 0);         // (0, 2)
-            slot(Y{}, Y{}, Y{}, mask_, N{}, N{}, N{}, N{}, I<1>{}, I<0>{}, I<2>{}, r0, 0, 0, 0, 0, 0, 0);                                            // (0, 3)
-            slot(Y{}, Y{}, Y{}, mask_, N{}, Y{}, N{}, N{}, I<0>{}, I<1>{}, I<3>{}, r0 + 32, 0, 0, o0 + 32 * PITCH, 0, 0, 0);                         // (1, 0)
-            slot(Y{}, Y{}, Y{}, mask_, N{}, N{}, Y{}, N{}, I<1>{}, I<2>{}, I<0>{}, r0 + 32, 0, 0, 0, p0, 0, 0);                                      // (1, 1)
+            slot(Y{}, Y{}, Y{}, mask_, N{}, Y{}, N{}, I<1>{}, I<0>{}, I<1>{}, I<3>{}, r0, 0, 0, o0, 0, p1, arow);                                       // (0, 0)
+            slot(Y{}, Y{}, Y{}, mask_, N{}, N{}, Y{}, I<2>{}, I<1>{}, I<2>{}, I<0>{}, r0, 0, 0, 0, p2 + 4 * PTILE, 0, arow);                               // (0, 1)
+            slot(Y{}, Y{}, Y{}, mask_, Y{}, N{}, N{}, I<0>{}, I<0>{}, I<3>{}, I<1>{}, r0, o0 + 32 * PITCH, o0 + 2 * TILE + 32 * 4, 0, 0, 0, 0);         // (0, 2)
+            slot(Y{}, Y{}, Y{}, mask_, N{}, N{}, N{}, I<0>{}, I<1>{}, I<0>{}, I<2>{}, r0, 0, 0, 0, 0, 0, 0);                                            // (0, 3)
+            slot(Y{}, Y{}, Y{}, mask_, N{}, Y{}, N{}, I<0>{}, I<0>{}, I<1>{}, I<3>{}, r0 + 32, 0, 0, o0 + 32 * PITCH, 0, 0, 0);                         // (1, 0)
+            slot(Y{}, Y{}, Y{}, mask_, N{}, N{}, Y{}, I<0>{}, I<1>{}, I<2>{}, I<0>{}, r0 + 32, 0, 0, 0, p0, 0, 0);                                      // (1, 1)
             store_tile(o2);
-            slot(Y{}, Y{}, Y{}, mask_, Y{}, N{}, N{}, N{}, I<0>{}, I<3>{}, I<1>{}, r0 + 32, o1, o1 + 2 * TILE, 0, 0, 0, 0);                          // (1, 2)
-            slot(Y{}, Y{}, Y{}, mask_, N{}, N{}, N{}, N{}, I<1>{}, I<0>{}, I<2>{}, r0 + 32, 0, 0, 0, 0, 0, 0);                                       // (1, 3)
+            slot(Y{}, Y{}, Y{}, mask_, Y{}, N{}, N{}, I<0>{}, I<0>{}, I<3>{}, I<1>{}, r0 + 32, o1, o1 + 2 * TILE, 0, 0, 0, 0);                          // (1, 2)
+            slot(Y{}, Y{}, Y{}, mask_, N{}, N{}, N{}, I<0>{}, I<1>{}, I<0>{}, I<2>{}, r0 + 32, 0, 0, 0, 0, 0, 0);                                       // (1, 3)
             __syncthreads();
             const int ot = o0, pt = p0;
             o0 = o1; o1 = o2; o2 = ot;
@@ -480,7 +519,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         tile(Y{}, t);   // the last tile: query rows past the end give probability zero
         // ---- drain: C of the last item, the flush of the last query block, the last two tiles' sums (after the rotation: p2 = the last tile's set,
         // p1 = the one before) ---------------------------------------------------------------------------------------------------------------------
-        slot(N{}, N{}, Y{}, N{}, N{}, N{}, N{}, N{}, I<0>{}, I<0>{}, I<3>{}, 0, 0, 0, 0, 0, 0, 0);
+        slot(N{}, N{}, Y{}, N{}, N{}, N{}, N{}, I<0>{}, I<0>{}, I<0>{}, I<3>{}, 0, 0, 0, 0, 0, 0, 0);
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (the last dQ MFMA was issued just above: let it write back before the flush reads)
         flush_tile(p2 + 4 * PTILE);
         __syncthreads();

@@ -178,6 +178,27 @@ def test_cu_seqlens_are_cached_per_lengths_and_uploads_pass_cpu_through():
     assert ops.h2d(t, "cpu") is t and ops.h2d(t, "cpu", torch.int32).dtype == torch.int32
 
 
+def test_attn_backward_workspace_query_matches_the_dispatch():
+    """acai_attn_varlen_bwd_workspace_bytes names the shapes the one-pass form takes: [total_q][H][32] fp32 for them, zero for the rest.  A host-side
+    function: no device is touched."""
+    from acai_omr_amd import _lib
+    L = _lib.lib()
+    bf, f32 = _lib.ACAI_BF16, _lib.ACAI_F32
+    q = lambda *a: int(L.acai_attn_varlen_bwd_workspace_bytes(*a))
+    #            B  H  dh  max_q max_k total_q total_k flags dtype p  pre
+    assert q(4, 16, 32, 4096, 4096, 16384, 16384, 0, bf, 0.0, 1) == 16384 * 16 * 32 * 4
+    assert q(4, 16, 32, 4096, 4096, 16384, 16384, 0, bf, 0.0, 0) == 0      # q not prescaled
+    assert q(4, 16, 32, 4096, 4096, 16384, 16384, 1, bf, 0.0, 1) == 0      # causal
+    assert q(4, 16, 32, 4096, 4096, 16384, 16384, 2, bf, 0.0, 1) == 0      # accumulating dk / dv
+    assert q(4, 16, 32, 4096, 4096, 16384, 16384, 0, bf, 0.1, 1) == 0      # dropout
+    assert q(4, 16, 32, 4096, 4096, 16384, 16384, 0, f32, 0.0, 1) == 0     # fp32
+    assert q(4, 16, 64, 4096, 4096, 16384, 16384, 0, bf, 0.0, 1) == 0      # d_h = 64
+    assert q(4, 16, 32, 4096, 4096, 16000, 16384, 0, bf, 0.0, 1) == 0      # ragged queries
+    assert q(4, 16, 32, 4096, 4096, 16384, 16000, 0, bf, 0.0, 1) == 0      # ragged keys
+    assert q(4, 16, 32, 4096, 4000, 16384, 16000, 0, bf, 0.0, 1) == 0      # keys not a multiple of 512
+    assert q(4, 16, 32, 256, 512, 1024, 2048, 0, bf, 0.0, 1) == 0          # short query side: the two-kernel form
+
+
 def test_asm_checks_flag_what_they_are_for():
     """acai_omr_amd/_asmcheck.py runs inside _lib.build() and fails the build: (1) a register written by an inline-asm load the compiler cannot
     see, touched before the kernel's counted vmcnt wait (the miscompile gemm_nt_pp_kernel once hit); (2) more LDS operations behind the staged

@@ -160,6 +160,57 @@ def test_attn_backward_wide_dh64_forms_equal_the_one_block_kernels(dev, tmp_path
     assert float(outs["0"]["dq"].float().abs().max()) < 6.0   # (every row was written: the 7.0 fill is gone)
 
 
+_BWD1P_SNIPPET = r"""
+import sys, torch
+from acai_omr_amd import engine, ops
+dev, bf, dh = "cuda", torch.bfloat16, 32
+out = {}
+for name, B, H, lq, lk in (("square", 3, 3, 1024, 1024), ("ragged_last_tile", 2, 2, 1000, 1536), ("smallest", 1, 1, 512, 512)):
+    E = H * dh
+    g = torch.Generator().manual_seed(lq + lk)
+    qkv = torch.randn(B * lk, 3 * E, generator=g).to(dev).to(bf)          # k, v: strided views of one buffer, like the in-projection's output
+    q = (torch.randn(B * lq, E, generator=g) * ops.QSCALE(dh)).to(dev).to(bf)
+    k, v = qkv[:, E:2 * E], qkv[:, 2 * E:]
+    do = torch.randn(B * lq, E, generator=g).to(dev).to(bf)
+    cu_q, cu_k = engine.cu_from_lens([lq] * B, dev), engine.cu_from_lens([lk] * B, dev)
+    lse = torch.empty(H * B * lq, device=dev)
+    o = ops.attn_varlen(q, k, v, cu_q, cu_k, H, dh, lq, lse=lse, q_prescaled=True)
+    dq, dkv = torch.full_like(q, 7.0), torch.full_like(qkv, 7.0)
+    for rep in range(2):   # (twice: the workspace is reused and must be re-zeroed by the call itself)
+        ops.attn_varlen_bwd(q, k, v, o, do, lse, cu_q, cu_k, H, dh, lq, lk, False, dq, dkv[:, E:2 * E], dkv[:, 2 * E:], q_prescaled=True)
+    torch.cuda.synchronize()
+    out[name] = {"dq": dq.cpu(), "dk": dkv[:, E:2 * E].cpu(), "dv": dkv[:, 2 * E:].cpu(), "untouched": dkv[:, :E].cpu()}
+torch.save(out, sys.argv[1])
+"""
+
+
+def test_attn_backward_one_pass_dh32_equals_the_two_kernel_form(dev, tmp_path):
+    """attn_bwd1p.hip (bf16, d_h = 32, prescaled q, equal-length sequences of a multiple of 512 keys): P and dS are formed once per score and
+    dQ is summed over the key blocks with fp32 atomics, so against the two-kernel form (ACAI_ATTN_BWD_1P=0) dK / dV agree to the last place
+    and dQ to the rounding of an fp32 sum taken in another order.  Query counts that end inside a 64-row tile, strided k / v / dk / dv views,
+    the smallest shape the form takes, and a second call over the same workspace.  The form is chosen once per process: child processes."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode in ("0", "1"):
+        f = tmp_path / f"p{mode}.pt"
+        env = dict(os.environ, ACAI_ATTN_BWD_1P=mode, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        r = subprocess.run([sys.executable, "-c", _BWD1P_SNIPPET, str(f)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = torch.load(f)
+    for case in outs["0"]:
+        two, one = outs["0"][case], outs["1"][case]
+        assert float((one["untouched"].float() - 7.0).abs().max()) == 0.0, case
+        for n in ("dq", "dk", "dv"):
+            a, b = two[n].float(), one[n].float()
+            assert float(b.abs().max()) < 6.0, (case, n)   # (every row was written: the 7.0 fill is gone)
+            d = (a - b).abs()
+            # one bf16 place of the larger magnitudes; dV comes from the same P packs in the same order
+            assert float(d.max()) <= 2.0 ** -7 * float(a.abs().max()), (case, n, float(d.max()))
+            if n == "dv":
+                assert float((d > 0).float().mean()) < 1e-3, (case, float((d > 0).float().mean()))
+
+
 @pytest.mark.parametrize("H,dh,S,B", [(16, 32, 4096, 2), (12, 64, 4096, 1)])
 def test_attn_prescaled_at_benchmark_size(dev, H, dh, S, B):
     """The attention kernels at the benchmarked sequence length (MAE decoder: 4096 tokens, 16 heads of 32; encoder: 12 heads of 64), bf16,
