@@ -43,6 +43,9 @@ typedef __attribute__((address_space(3))) s4 *lds_s4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define ACAI_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef ACAI_1P_ABL   // timing ablations (tools/build_variant.sh ... -DACAI_1P_ABL=bits; WRONG results): 1 no barrier in the loop, 2 no atomics, 4 no sums,
+#define ACAI_1P_ABL 0 // 8 no flush, 16 no dS image traffic, 32 no statistics reads
+#endif
 
 // acc (accumulator registers) += A . B, both operands architectural.  NOP: "s_nop 1" in front (a VALU write - the compiler's tuple copies at region
 // edges sit directly in front of an asm statement - needs two wait states before an MFMA reads the register: attn_bwd64w.hip).  The steady-state
@@ -117,10 +120,12 @@ __device__ __forceinline__ void e_ops(f32x16 &s, f32x16 &p, uint32_t (&xp)[8], u
         e_ops<OP + 1, END, MASK>(s, p, xp, xs, row0, lh, rows);
     }
 }
-template <int G, bool MASK>   // operations of MFMA gap G of a slot: ten gaps, 5 5 5 5 5 5 5 5 4 4
+// operations of MFMA gap G of a slot, dealt by issue TIME (an exp2 holds the issue port 8 cycles, the rest 4; an MFMA wants its predecessor 32 cycles
+// back): 3 3 4 5 5 5 5 5 6 7 - the first gaps also carry the slot's LDS instructions, the last ones nothing else
+template <int G, bool MASK>
 __device__ __forceinline__ void e_gap(f32x16 &s, f32x16 &p, uint32_t (&xp)[8], uint32_t (&xs)[8], int row0, int lh, int rows) {
-    constexpr int a = G < 8 ? 5 * G : 40 + 4 * (G - 8), b = G < 8 ? a + 5 : a + 4;
-    e_ops<a, b, MASK>(s, p, xp, xs, row0, lh, rows);
+    constexpr int start[11] = {0, 3, 6, 10, 15, 20, 25, 30, 35, 41, 48};
+    e_ops<start[G], start[G + 1], MASK>(s, p, xp, xs, row0, lh, rows);
 }
 
 __device__ __forceinline__ uint4 x4(const uint32_t (&x)[8], int h) { return make_uint4(x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]); }
@@ -309,6 +314,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(DQ32, 0, lq > 0 ? ((lq - 1) * ldq32 + 32) * 4 : 0, 0x00020000);
     float ra[8][4];   // partial-tile elements between their LDS read and their add (a few gaps: the register allocator sees short live ranges)
     auto flush_piece = [&](int pset_qb, int g4) {   // (constant g4 at every call)
+        if constexpr (ACAI_1P_ABL & 8) return;
         unsigned char *pt = lds + pset_qb + pflush_v + 32 * g4;
         switch (g4) {
             case 0: *reinterpret_cast<f32x4 *>(pt) = f32x4{dqa[0], dqa[1], dqa[2], dqa[3]}; break;
@@ -355,6 +361,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         TF dst[2];   // dS^T fragments of item w-1
         auto red = [&](auto g_) __attribute__((always_inline)) {   // REDUCE: 1 = the tile's first slot, 2 = its second (the last two elements' adds)
             constexpr int g = decltype(g_)::value;
+            if constexpr (ACAI_1P_ABL & 4) return;
             if constexpr (REDUCE == 1 && g < 8) {
                 const unsigned char *pp = lds + pred + pred_v + (g >> 2) * 4 * PTILE + (4 * (g & 1) + 16 * ((g >> 1) & 1)) * PROW * 4;
 #pragma unroll
@@ -363,7 +370,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             constexpr int n = REDUCE == 1 ? g - 4 : g + 6;
             if constexpr ((REDUCE == 1 && g >= 4) || (REDUCE == 2 && g < 2)) {
                 const float sum = (ra[n][0] + ra[n][1]) + (ra[n][2] + ra[n][3]);
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(sum, rA, avoff, arow + (8 * (n >> 2) + (n & 1) + 4 * ((n >> 1) & 1)) * row4, 0);
+                if constexpr (ACAI_1P_ABL & 2) asm volatile("" ::"v"(sum));
+                else __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(sum, rA, avoff, arow + (8 * (n >> 2) + (n & 1) + 4 * ((n >> 1) & 1)) * row4, 0);
             }
         };
         // gap 0: A, S k-step 0 | the second half of the dS image of item w-1 -> LDS (the first went out in its own E phase, gap 6: LDS writes move
@@ -372,7 +380,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if constexpr (HA) mma_ab0<NP>(sA, qr[0], kf[jA][0], nl);
         ACAI_SB();
         if constexpr (HE) e_gap<0, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
-        if constexpr (HC) *reinterpret_cast<uint4 *>(dsimg + dsw[1]) = x4(xsC, 1);
+        if constexpr (HC && !(ACAI_1P_ABL & 16)) *reinterpret_cast<uint4 *>(dsimg + dsw[1]) = x4(xsC, 1);
         if constexpr (LOADROW) qr[0] = read_r(rowp, 0);
         red(I<0>{});
         ACAI_SB();
@@ -380,10 +388,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if constexpr (HC) mma_acc<NP>(dv[jC], dot[0].u, x4(xpC, 0));
         ACAI_SB();
         if constexpr (HE) e_gap<1, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
-        if constexpr (HC) dst[0] = read_td(dsimg, 0);
+        if constexpr (HC && !(ACAI_1P_ABL & 16)) dst[0] = read_td(dsimg, 0);
+        if constexpr (HC && (ACAI_1P_ABL & 16)) dst[0].u = make_uint4(xsC[0], xsC[1], xsC[2], xsC[3]);
         if constexpr (LOADROW) {
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) read_init(nl, nextstat, g4);
+            for (int g4 = 0; g4 < 4; ++g4)
+                if constexpr (!(ACAI_1P_ABL & 32)) read_init(nl, nextstat, g4);
         }
         if constexpr (LOADT) dot[0] = read_t(tp + TILE, 0);
         red(I<1>{});
@@ -392,7 +402,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if constexpr (HA) mma_ab0<NP>(pA, dor[0], vf[jA][0], nd);
         ACAI_SB();
         if constexpr (HE) e_gap<2, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
-        if constexpr (HC) dst[1] = read_td(dsimg, 1);
+        if constexpr (HC && !(ACAI_1P_ABL & 16)) dst[1] = read_td(dsimg, 1);
+        if constexpr (HC && (ACAI_1P_ABL & 16)) dst[1].u = make_uint4(xsC[4], xsC[5], xsC[6], xsC[7]);
         if constexpr (LOADROW) dor[0] = read_r(rowp + TILE, 0);
         if constexpr (FLUSH) flush_piece(pflush, 0);   // (the block's last dQ MFMA is three MFMAs back; the next one that writes dqa is gap 7's)
         red(I<2>{});
@@ -403,7 +414,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if constexpr (HE) e_gap<3, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
         if constexpr (LOADROW) {
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) read_init(nd, nextstat + QT * 4, g4);
+            for (int g4 = 0; g4 < 4; ++g4)
+                if constexpr (!(ACAI_1P_ABL & 32)) read_init(nd, nextstat + QT * 4, g4);
         }
         if constexpr (LOADT) dot[1] = read_t(tp + TILE, 1);
         if constexpr (FLUSH) flush_piece(pflush, 1);
@@ -429,7 +441,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if constexpr (HA) mma_ab<NP>(pA, dor[1], vf[jA][1]);
         ACAI_SB();
         if constexpr (HE) e_gap<6, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
-        if constexpr (HE) *reinterpret_cast<uint4 *>(dsreg + pE * (32 * PITCH) + dsw[0]) = x4(xsE, 0);   // (its last pair was packed in gap 5)
+        if constexpr (HE && !(ACAI_1P_ABL & 16)) *reinterpret_cast<uint4 *>(dsreg + pE * (32 * PITCH) + dsw[0]) = x4(xsE, 0);   // (its last pair is packed first thing in this gap)
         if constexpr (LOADROW) dor[1] = read_r(rowp + TILE, 1);
         red(I<6>{});
         ACAI_SB();
@@ -506,7 +518,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             store_tile(o2);
             slot(Y{}, Y{}, Y{}, mask_, Y{}, N{}, N{}, I<0>{}, I<0>{}, I<3>{}, I<1>{}, r0 + 32, o1, o1 + 2 * TILE, 0, 0, 0, 0);                          // (1, 2)
             slot(Y{}, Y{}, Y{}, mask_, N{}, N{}, N{}, I<0>{}, I<1>{}, I<0>{}, I<2>{}, r0 + 32, 0, 0, 0, 0, 0, 0);                                       // (1, 3)
-            __syncthreads();
+            if constexpr (!(ACAI_1P_ABL & 1)) __syncthreads();
             const int ot = o0, pt = p0;
             o0 = o1; o1 = o2; o2 = ot;
             p0 = p1; p1 = p2; p2 = pt;

@@ -9,7 +9,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc*_*"))):
     for f in files:
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "attn_" not in k:
+            if "attn_" not in k and "bwd1p" not in k:
                 continue
             m = re.search(r"(attn_\w+)<([^>]*)>", k)
             short = m.group(1) + "<" + m.group(2).replace("unsigned short", "bf16") + ">" if m else re.sub(r"\(anonymous namespace\)::", "", k).split("(")[0][:60]
