@@ -1,6 +1,6 @@
 // fp32 no-return atomic adds in the one-pass attention backward's pattern, alone: every workgroup of 256 threads walks the [4096 q][H][32] fp32 rows of
 // its (sequence, head) in 64-row tiles, lanes along d (a wave instruction = two 128-byte row segments); the 8 (or 16) key-block workgroups of a
-// (sequence, head) add to the same rows.  hipcc -O3 --offload-arch=gfx950 -o /tmp/atomic_rate tools/experiments/atomic_rate.hip
+// (sequence, head) add to the same rows.  hipcc -O3 --offload-arch=gfx950 -o tools/experiments/atomic_rate.bin tools/experiments/atomic_rate.hip (the .bin is git-ignored; gpurun -- tools/experiments/atomic_rate.bin)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __global__ __launch_bounds__(256) void k(float *buf, int H, int nblk, int rows, int swz) {

@@ -1,5 +1,5 @@
 // LDS access patterns of attn_bwd1p.hip timed in isolation: one wave, 64 x 32 back-to-back instructions of one pattern, cycles per instruction.
-//   hipcc -O3 --offload-arch=gfx950 -o /tmp/lds_patterns tools/experiments/lds_patterns.hip && /tmp/lds_patterns
+//   hipcc -O3 --offload-arch=gfx950 -o tools/experiments/lds_patterns.bin tools/experiments/lds_patterns.hip (the .bin is git-ignored; gpurun -- tools/experiments/lds_patterns.bin)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
