@@ -929,6 +929,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 }
 
 // the shapes the one-pass kernel takes (beyond bf16 / prescaled / no dropout / aligned operands, which the dispatch checks by its template arguments)
+inline bool bwd1p_enabled() {   // ACAI_ATTN_BWD_1P=0: keep the two-kernel form (read once per process)
+    static const bool on = !(getenv("ACAI_ATTN_BWD_1P") && atoi(getenv("ACAI_ATTN_BWD_1P")) == 0);
+    return on;
+}
 inline bool bwd1p_shape_ok(int dh, int causal, int accum, int B, int H, int max_q, int max_k, int total_q, int total_k) {
     // every sequence max_q queries and max_k keys long (the kernel has no partial key blocks, and its first tiles add zeros to the first 64 query
     // rows); 32-bit byte offsets into one sequence's [max_q][H][32] fp32 rows
@@ -966,8 +970,7 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, bool pre, void *ws
             // one pass over the scores (attn_bwd1p.hip) when the caller lent a workspace and the shape allows: every sequence max_k keys, a
             // multiple of 512 (ACAI_ATTN_BWD_1P=0: keep the two kernels below, whose dQ is bit-reproducible - the one-pass form adds the key
             // blocks' contributions to a query's gradient in arrival order)
-            static const int onepass_env = getenv("ACAI_ATTN_BWD_1P") ? atoi(getenv("ACAI_ATTN_BWD_1P")) : 1;
-            if (onepass_env && bwd1p_shape_ok(a.dh, a.causal, a.accum_dkv, B, a.H, max_q, max_k, a.total_q, total_k) && ws && ws_bytes >= acai_attn_bwd1p_workspace(a.total_q, a.H)) {
+            if (bwd1p_enabled() && bwd1p_shape_ok(a.dh, a.causal, a.accum_dkv, B, a.H, max_q, max_k, a.total_q, total_k) && ws && ws_bytes >= acai_attn_bwd1p_workspace(a.total_q, a.H)) {
                 acai_attn_bwd1p_launch(a, B, max_k, ws, st);
                 return;
             }
@@ -1059,7 +1062,7 @@ extern "C" int acai_attn_varlen_bwd_ws(const void *q, int ldq, const void *k, in
 extern "C" size_t acai_attn_varlen_bwd_workspace_bytes(int B, int H, int dh, int max_q, int max_k, int total_q, int total_k, int causal, int dtype,
                                                        float dropout_p, int q_prescaled) {
     if (dtype != ACAI_BF16 || !q_prescaled || dropout_p != 0.f || B <= 0 || H <= 0 || total_q <= 0) return 0;
-    if (getenv("ACAI_ATTN_BWD_1P") && atoi(getenv("ACAI_ATTN_BWD_1P")) == 0) return 0;
+    if (!bwd1p_enabled()) return 0;
     return bwd1p_shape_ok(dh, causal & 1, (causal >> 1) & 1, B, H, max_q, max_k, total_q, total_k) ? acai_attn_bwd1p_workspace(total_q, H) : 0;
 }
 
