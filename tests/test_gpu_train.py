@@ -65,6 +65,10 @@ def test_gemm_transposed_variants(dev, M, N, K, dtype):
     (1, 64, [1025], [512], False),
     (1, 64, [512], [330], False),
     (3, 64, [768], [129], False),
+    # d_h = 32, bf16 prescaled, no mask, equal-length sequences with a multiple of 512 keys: the one-pass backward (attn_bwd1p.hip) against the
+    # fp64 autograd reference - square, a query count that ends inside a 64-row tile, more keys than queries
+    (2, 32, [1024, 1024], None, False),
+    (3, 32, [600, 600], [1536, 1536], False),
 ])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("prescaled", [False, True])
