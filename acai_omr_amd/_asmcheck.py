@@ -115,7 +115,7 @@ def _regs_va(text):
     return used
 
 
-def check_asm_mfma_operands(src, kernels=r"_ZN12_GLOBAL__N_1\d+attn_(?:fwd64w|bwd64w_dq|bwd64w_dkv|bwd1p)_kernel", need=2):
+def check_asm_mfma_operands(src, kernels=r"_ZN12_GLOBAL__N_1\d+attn_(?:fwd64w|bwd64w_dq|bwd64w_dkv|bwd1p)_kernel(?:ILb[01]EE)?", need=2):
     """Every `v_mfma*` between ;;#ASMSTART / ;;#ASMEND: the VALU instructions within `need` wait states in front of it (s_nop inside the asm
     statement included) must not write its A / B / C source registers."""
     problems, n = [], 0

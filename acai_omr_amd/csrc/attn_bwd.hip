@@ -934,10 +934,10 @@ inline bool bwd1p_enabled() {   // ACAI_ATTN_BWD_1P=0: keep the two-kernel form 
     return on;
 }
 inline bool bwd1p_shape_ok(int dh, int causal, int accum, int B, int H, int max_q, int max_k, int total_q, int total_k) {
-    // every sequence max_q queries and max_k keys long (the kernel has no partial key blocks, and its first tiles add zeros to the first 64 query
-    // rows); 32-bit byte offsets into one sequence's [max_q][H][32] fp32 rows
-    return dh == 32 && !causal && !accum && max_k >= 512 && max_k % 512 == 0 && max_q >= 512 && total_k > 0 && (long long)B * max_k == (long long)total_k &&
-           (long long)B * max_q == (long long)total_q && (long long)max_q * H * 128 < 0x7FFFFF00ll;
+    // long sequences only (short ones keep the two-kernel form: a workgroup's prologue weighs more); 32-bit byte offsets into one sequence's
+    // [max_q][H][32] fp32 rows
+    (void)B; (void)total_q; (void)total_k;
+    return dh == 32 && !causal && !accum && max_k >= 512 && max_q >= 512 && (long long)(max_q + 64) * H * 128 < 0x7FFFFF00ll;
 }
 
 template <typename T, int DHP>
@@ -967,11 +967,12 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, bool pre, void *ws
                 hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
                 hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             }
-            // one pass over the scores (attn_bwd1p.hip) when the caller lent a workspace and the shape allows: every sequence max_k keys, a
-            // multiple of 512 (ACAI_ATTN_BWD_1P=0: keep the two kernels below, whose dQ is bit-reproducible - the one-pass form adds the key
+            // one pass over the scores (attn_bwd1p.hip) when the caller lent a workspace and the sequences are long (ACAI_ATTN_BWD_1P=0: keep the two kernels below, whose dQ is bit-reproducible - the one-pass form adds the key
             // blocks' contributions to a query's gradient in arrival order)
             if (bwd1p_enabled() && bwd1p_shape_ok(a.dh, a.causal, a.accum_dkv, B, a.H, max_q, max_k, a.total_q, total_k) && ws && ws_bytes >= acai_attn_bwd1p_workspace(a.total_q, a.H)) {
-                acai_attn_bwd1p_launch(a, B, max_k, ws, st);
+                // (when the host can tell that every sequence is max_k keys long, a multiple of 512, the partial-block launch is left out)
+                const bool eq = total_k > 0 && (long long)B * max_k == (long long)total_k && (long long)B * max_q == (long long)a.total_q;
+                acai_attn_bwd1p_launch(a, B, max_k, eq && max_k % 512 == 0 ? 0 : 1, eq ? 1 : 0, ws, st);
                 return;
             }
             if (nq_env == 2 && !a.causal && !a.accum_dkv && max_q >= 512 && max_k >= 512) {

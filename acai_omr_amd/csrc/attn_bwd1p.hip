@@ -1,5 +1,5 @@
-// Varlen attention BACKWARD in ONE PASS, bf16, d_h = 32, q prescaled, no dropout, no causal mask, every sequence a multiple of 512 keys (the MAE
-// decoder's self-attention at its benchmarked shapes: acai_omr/models/models.py:186-190; backward call site acai_omr/train/pre_train.py:59).
+// Varlen attention BACKWARD in ONE PASS, bf16, d_h = 32, q prescaled, no dropout, no causal mask; ragged sequences (the MAE decoder's
+// self-attention: acai_omr/models/models.py:186-190; backward call site acai_omr/train/pre_train.py:59).
 //
 // attn_bwd.hip runs two kernels - dQ with the query on the lane, dK / dV with the key on the lane - and each recomputes S and P: seven products and two
 // exponentials per score, and at d_h = 32 those kernels are bound by VALU issue (one exp2 + one multiply + packs per score AND kernel).  This kernel
@@ -92,15 +92,15 @@ __device__ __forceinline__ void mma_ab(f32x16 &d, const uint4 &a, const u32x4 &b
 }
 
 // The VALU stream of one work item as 48 numbered single-issue operations (attn_bwd64w.hip: dkv_op):
-//   e(i): s[i] = P = 2^s[i] (MASK: 0 unless the query row exists); m(i): p[i] = dS = s[i] p[i]; kP(n) / kS(n): bf16 pairs of P / dS
+//   e(i): s[i] = P = 2^s[i] (MASK: 0 unless the query row - and, in the partial-block kernel, the lane's key - exists); m(i): p[i] = dS = s[i] p[i]; kP(n) / kS(n): bf16 pairs of P / dS
 //   e0 e1 | e2 e3 m0 m1 kP0 kS0 | ... | e14 e15 m12 m13 kP6 kS6 | m14 m15 kP7 kS7
 template <int OP, bool MASK>
-__device__ __forceinline__ void e_op(f32x16 &s, f32x16 &p, uint32_t (&xp)[8], uint32_t (&xs)[8], int row0, int lh, int rows) {
+__device__ __forceinline__ void e_op(f32x16 &s, f32x16 &p, uint32_t (&xp)[8], uint32_t (&xs)[8], int row0, int lh, int rows, bool kok) {
     constexpr int r = OP - 2, step = OP < 2 ? 0 : 1 + r / 6, w = OP < 2 ? OP : r % 6;
     if constexpr (step == 0 || (step < 8 && w < 2)) {
         constexpr int i = 2 * step + w;
         float v = fast_exp2(s[i]);
-        if constexpr (MASK) v = (row0 + (i & 3) + 8 * (i >> 2) + 4 * lh) < rows ? v : 0.f;
+        if constexpr (MASK) v = ((row0 + (i & 3) + 8 * (i >> 2) + 4 * lh) < rows && kok) ? v : 0.f;
         s[i] = v;
     } else if constexpr (step < 8 ? w < 4 : w < 2) {
         constexpr int i = 2 * (step - 1) + (step < 8 ? w - 2 : w);
@@ -114,18 +114,18 @@ __device__ __forceinline__ void e_op(f32x16 &s, f32x16 &p, uint32_t (&xp)[8], ui
     }
 }
 template <int OP, int END, bool MASK>
-__device__ __forceinline__ void e_ops(f32x16 &s, f32x16 &p, uint32_t (&xp)[8], uint32_t (&xs)[8], int row0, int lh, int rows) {
+__device__ __forceinline__ void e_ops(f32x16 &s, f32x16 &p, uint32_t (&xp)[8], uint32_t (&xs)[8], int row0, int lh, int rows, bool kok) {
     if constexpr (OP < END) {
-        e_op<OP, MASK>(s, p, xp, xs, row0, lh, rows);
-        e_ops<OP + 1, END, MASK>(s, p, xp, xs, row0, lh, rows);
+        e_op<OP, MASK>(s, p, xp, xs, row0, lh, rows, kok);
+        e_ops<OP + 1, END, MASK>(s, p, xp, xs, row0, lh, rows, kok);
     }
 }
 // operations of MFMA gap G of a slot, dealt by issue TIME (an exp2 holds the issue port 8 cycles, the rest 4; an MFMA wants its predecessor 32 cycles
 // back): 3 3 4 5 5 5 5 5 6 7 - the first gaps also carry the slot's LDS instructions, the last ones nothing else
 template <int G, bool MASK>
-__device__ __forceinline__ void e_gap(f32x16 &s, f32x16 &p, uint32_t (&xp)[8], uint32_t (&xs)[8], int row0, int lh, int rows) {
+__device__ __forceinline__ void e_gap(f32x16 &s, f32x16 &p, uint32_t (&xp)[8], uint32_t (&xs)[8], int row0, int lh, int rows, bool kok) {
     constexpr int start[11] = {0, 3, 6, 10, 15, 20, 25, 30, 35, 41, 48};
-    e_ops<start[G], start[G + 1], MASK>(s, p, xp, xs, row0, lh, rows);
+    e_ops<start[G], start[G + 1], MASK>(s, p, xp, xs, row0, lh, rows, kok);
 }
 
 __device__ __forceinline__ uint4 x4(const uint32_t (&x)[8], int h) { return make_uint4(x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]); }
@@ -140,7 +140,11 @@ union TF { s4 v[2]; uint4 u; };
 __global__ __launch_bounds__(256) void bwd1p_delta_kernel(BwdArgs a, float *dq32, int rows) {
     const int t = blockIdx.x * 256 + threadIdx.x, sub = t & 3, pair = t >> 2;   // four lanes per (row, head): 16 bytes each
     const int row = pair / a.H, h = pair % a.H;
-    if (row >= rows) return;
+    if (row >= rows + 64) return;
+    float4 *z = reinterpret_cast<float4 *>(dq32 + ((size_t)row * a.H + h) * 32 + sub * 8);
+    z[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    z[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row >= rows) return;   // (the workspace's 64 padding rows)
     const uint4 o = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16_t *>(a.o) + (size_t)row * a.ldo + h * 32 + sub * 8);
     const uint4 d = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16_t *>(a.dout) + (size_t)row * a.lddo + h * 32 + sub * 8);
     const uint32_t ow[4] = {o.x, o.y, o.z, o.w}, dw[4] = {d.x, d.y, d.z, d.w};
@@ -153,9 +157,6 @@ __global__ __launch_bounds__(256) void bwd1p_delta_kernel(BwdArgs a, float *dq32
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
     if (sub == 0) const_cast<float *>(a.delta)[(size_t)h * a.total_q + row] = -s;
-    float4 *z = reinterpret_cast<float4 *>(dq32 + ((size_t)row * a.H + h) * 32 + sub * 8);
-    z[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-    z[1] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // ---- dq[q][h * 32 + d] = bf16(scale * dq32[q][h][d]) --------------------------------------------------------------------------------------
@@ -173,20 +174,15 @@ __global__ __launch_bounds__(256) void bwd1p_scale_kernel(BwdArgs a, const float
     *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(a.dq) + (size_t)row * a.lddq + h * 32 + sub * 8) = r;
 }
 
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd1p_kernel(BwdArgs a, float *dq32) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+// One workgroup's work: 512 keys (k0 ...) of sequence b, head h.  KM = false: a FULL block.  KM = true: the keys past a sequence's last full block -
+// lanes whose key does not exist read the last key's row and are masked out of P in every tile; this instantiation runs the masked tile body only,
+// so each body still has ONE steady-state tile variant (see the header).
+template <bool KM>
+__device__ __forceinline__ void bwd1p_body(const BwdArgs &a, float *dq32, unsigned char *lds, int b, int h, int k0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
-    int vid = blockIdx.x;
-    {   // XCD-aware block order (see attn_fwd64w.hip): the key blocks of one (sequence, head) stream the same Q / dO tiles
-        const int per = gridDim.x >> 3;
-        if (vid < (per << 3)) vid = (vid & 7) * per + (vid >> 3);
-    }
-    const int kb = vid % a.nblk, h = (vid / a.nblk) % a.H, b = vid / (a.nblk * a.H);
     const int q_start = a.cu_q[b], lq = a.cu_q[b + 1] - q_start;
     const int k_start = a.cu_k[b], lk = a.cu_k[b + 1] - k_start;
-    const int k0 = kb * KBG;
-    if (k0 + KBG > lk) return;   // (the host launches this form only when every sequence is a multiple of 512 keys)
 
     const bf16_t *Q = reinterpret_cast<const bf16_t *>(a.q) + (size_t)q_start * a.ldq + h * 32;
     const bf16_t *K = reinterpret_cast<const bf16_t *>(a.k) + (size_t)k_start * a.ldk + h * 32;
@@ -234,10 +230,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
     // ---- lane-owned keys: K / V fragments (B operands of S = Q K^T, dP = dO V^T) --------------------------------------------------------------------
     u32x4 kf[4][2], vf[4][2];
+    int kmask = 0;   // KM: bit j = the lane's key of owned block j exists
     unsigned char *kimg = lds + LDS_P + wave * (KBW * PITCH);   // the wave's 128 K rows, natural image, for the prologue only (partial-tile set 0 later)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int key = k0 + wave * KBW + j * 32 + lr;   // (< lk: the block is full)
+        int key = k0 + wave * KBW + j * 32 + lr;   // (KM = false: < lk, the block is full)
+        if constexpr (KM) {
+            kmask |= (key < lk ? 1 : 0) << j;
+            key = key < lk ? key : lk - 1;
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const uint4 kk = *reinterpret_cast<const uint4 *>(K + (size_t)key * a.ldk + s * 16 + lh * 8);
@@ -353,7 +354,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         constexpr bool LOADROW = decltype(loadrow_)::value, LOADT = decltype(loadt_)::value, FLUSH = decltype(flush_)::value;
         constexpr int REDUCE = decltype(reduce_)::value;
         constexpr int pE = decltype(pE_)::value, jA = decltype(jA_)::value, jC = decltype(jC_)::value;
-        constexpr bool NP = M || !HE || !HA || !HC;   // outside the steady-state loop the compiler's tuple copies at region edges may sit in front of an MFMA: pad
+        constexpr bool NP = M || !HE || !HA || !HC;
+   // outside the steady-state loop the compiler's tuple copies at region edges may sit in front of an MFMA: pad
+        const bool kokE = !KM || ((kmask >> ((jA + 3) & 3)) & 1);   // item w's owned block is the one before A's
         f32x16 &sE = sc[pE], &pEd = dp[pE], &sA = sc[pE ^ 1], &pA = dp[pE ^ 1];
         uint32_t(&xpE)[8] = xp[pE], (&xsE)[8] = xs[pE], (&xpC)[8] = xp[pE ^ 1], (&xsC)[8] = xs[pE ^ 1];
         unsigned char *dsimg = dsreg + (pE ^ 1) * (32 * PITCH);
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // dK product reads - q in the order 16 P + 8 gl + 4 lh + i at column 16 P + 8 lh + 4 gl + i (bits 2 and 3 swapped), which the flush undoes
         if constexpr (HA) mma_ab0<NP>(sA, qr[0], kf[jA][0], nl);
         ACAI_SB();
-        if constexpr (HE) e_gap<0, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
+        if constexpr (HE) e_gap<0, M>(sE, pEd, xpE, xsE, rowE, lh, lq, kokE);
         if constexpr (HC && !(ACAI_1P_ABL & 16)) *reinterpret_cast<uint4 *>(dsimg + dsw[1]) = x4(xsC, 1);
         if constexpr (LOADROW) qr[0] = read_r(rowp, 0);
         red(I<0>{});
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // gap 1: C, dV k-step 0
         if constexpr (HC) mma_acc<NP>(dv[jC], dot[0].u, x4(xpC, 0));
         ACAI_SB();
-        if constexpr (HE) e_gap<1, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
+        if constexpr (HE) e_gap<1, M>(sE, pEd, xpE, xsE, rowE, lh, lq, kokE);
         if constexpr (HC && !(ACAI_1P_ABL & 16)) dst[0] = read_td(dsimg, 0);
         if constexpr (HC && (ACAI_1P_ABL & 16)) dst[0].u = make_uint4(xsC[0], xsC[1], xsC[2], xsC[3]);
         if constexpr (LOADROW) {
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // gap 2: A, dP k-step 0
         if constexpr (HA) mma_ab0<NP>(pA, dor[0], vf[jA][0], nd);
         ACAI_SB();
-        if constexpr (HE) e_gap<2, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
+        if constexpr (HE) e_gap<2, M>(sE, pEd, xpE, xsE, rowE, lh, lq, kokE);
         if constexpr (HC && !(ACAI_1P_ABL & 16)) dst[1] = read_td(dsimg, 1);
         if constexpr (HC && (ACAI_1P_ABL & 16)) dst[1].u = make_uint4(xsC[4], xsC[5], xsC[6], xsC[7]);
         if constexpr (LOADROW) dor[0] = read_r(rowp + TILE, 0);
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // gap 3: C, dV k-step 1
         if constexpr (HC) mma_acc<NP>(dv[jC], dot[1].u, x4(xpC, 1));
         ACAI_SB();
-        if constexpr (HE) e_gap<3, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
+        if constexpr (HE) e_gap<3, M>(sE, pEd, xpE, xsE, rowE, lh, lq, kokE);
         if constexpr (LOADROW) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4)
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // gap 4: A, S k-step 1
         if constexpr (HA) mma_ab<NP>(sA, qr[1], kf[jA][1]);
         ACAI_SB();
-        if constexpr (HE) e_gap<4, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
+        if constexpr (HE) e_gap<4, M>(sE, pEd, xpE, xsE, rowE, lh, lq, kokE);
         if constexpr (LOADROW) qr[1] = read_r(rowp, 1);
         if constexpr (FLUSH) flush_piece(pflush, 2);
         red(I<4>{});
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // gap 5: C, dK k-step 0
         if constexpr (HC) mma_acc<NP>(dk[jC], qt[0].u, x4(xsC, 0));
         ACAI_SB();
-        if constexpr (HE) e_gap<5, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
+        if constexpr (HE) e_gap<5, M>(sE, pEd, xpE, xsE, rowE, lh, lq, kokE);
         if constexpr (LOADT) qt[0] = read_t(tp, 0);
         if constexpr (FLUSH) flush_piece(pflush, 3);
         red(I<5>{});
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // gap 6: A, dP k-step 1
         if constexpr (HA) mma_ab<NP>(pA, dor[1], vf[jA][1]);
         ACAI_SB();
-        if constexpr (HE) e_gap<6, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
+        if constexpr (HE) e_gap<6, M>(sE, pEd, xpE, xsE, rowE, lh, lq, kokE);
         if constexpr (HE && !(ACAI_1P_ABL & 16)) *reinterpret_cast<uint4 *>(dsreg + pE * (32 * PITCH) + dsw[0]) = x4(xsE, 0);   // (its last pair is packed first thing in this gap)
         if constexpr (LOADROW) dor[1] = read_r(rowp + TILE, 1);
         red(I<6>{});
@@ -451,20 +454,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             else mma_acca<NP>(dqa, ktf[jC][0], dst[0].u);
         }
         ACAI_SB();
-        if constexpr (HE) e_gap<7, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
+        if constexpr (HE) e_gap<7, M>(sE, pEd, xpE, xsE, rowE, lh, lq, kokE);
         red(I<7>{});
         ACAI_SB();
         // gap 8: C, dK k-step 1 (between the two dQ k-steps: a dependent MFMA directly behind its producer waits for the whole pass)
         if constexpr (HC) mma_acc<NP>(dk[jC], qt[1].u, x4(xsC, 1));
         ACAI_SB();
-        if constexpr (HE) e_gap<8, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
+        if constexpr (HE) e_gap<8, M>(sE, pEd, xpE, xsE, rowE, lh, lq, kokE);
         if constexpr (LOADT) qt[1] = read_t(tp, 1);
         red(I<8>{});
         ACAI_SB();
         // gap 9: C, dQ k-step 1
         if constexpr (HC) mma_acca<NP>(dqa, ktf[jC][1], dst[1].u);
         ACAI_SB();
-        if constexpr (HE) e_gap<9, M>(sE, pEd, xpE, xsE, rowE, lh, lq);
+        if constexpr (HE) e_gap<9, M>(sE, pEd, xpE, xsE, rowE, lh, lq, kokE);
         red(I<9>{});
         ACAI_SB();
     };
@@ -526,9 +529,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // (the next tile's first query block is read during this tile's last slots and the next tile's first: it was stored during tile t-1 and
         // published by that tile's barrier; tile t+2 is stored in this tile's sixth slot into the slot tile t-1 left; past the last tile the ring holds
         // zeros - buffer loads beyond the end - and the extra A of the last slot feeds nothing)
-        int t = 0;
-        for (; t + 1 < nqt; ++t) tile(N{}, t);
-        tile(Y{}, t);   // the last tile: query rows past the end give probability zero
+        if constexpr (KM) {
+            for (int t = 0; t < nqt; ++t) tile(Y{}, t);
+        } else {
+            int t = 0;
+            for (; t + 1 < nqt; ++t) tile(N{}, t);
+            tile(Y{}, t);   // the last tile: query rows past the end give probability zero
+        }
         // ---- drain: C of the last item, the flush of the last query block, the last two tiles' sums (after the rotation: p2 = the last tile's set,
         // p1 = the one before) ---------------------------------------------------------------------------------------------------------------------
         slot(N{}, N{}, Y{}, N{}, N{}, N{}, N{}, I<0>{}, I<0>{}, I<0>{}, I<3>{}, 0, 0, 0, 0, 0, 0, 0);
@@ -544,6 +551,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int key = k0 + wave * KBW + j * 32 + lr;
+        if (KM && key >= lk) continue;
         bf16_t *rk = DK + (size_t)key * a.lddk, *rv = DV + (size_t)key * a.lddv;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -558,19 +566,43 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 }
 
+// Grid: slots x H x B with slots = max_k / 512 (+ 1 when a sequence may end inside a block), the key-block slot fastest: the workgroups of one
+// (sequence, head) run together and stream the same Q / dO tiles.  tail256 != 0 (equal-length batch): the XCD-aware block order of attn_fwd64w.hip on
+// top - each XCD takes a contiguous eighth of the (sequence, head) pairs and its L2 serves the shared tiles.  On a RAGGED batch that static split
+// leaves the XCD with the longest sequences working alone at the end, so the plain order is used.  Measured (one box): equal-length 32 x 16 x 4096^2
+// 2.97-3.00 ms with the XCD order, 3.10 without; 16 sequences of 1024 ... 9216 tokens 2.53 ms plain, 3.47 with the XCD order; and with the SEQUENCE
+// index fastest and the slots descending (longest workgroups first) 5.95 / 3.21 ms - the workgroups of a (sequence, head) must run together.
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd1p_kernel(BwdArgs a, float *dq32) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    int vid = blockIdx.x;
+    if (a.tail256) {
+        const int per = gridDim.x >> 3;
+        if (vid < (per << 3)) vid = (vid & 7) * per + (vid >> 3);
+    }
+    const int kb = vid % a.nblk, h = (vid / a.nblk) % a.H, b = vid / (a.nblk * a.H);
+    const int lk = a.cu_k[b + 1] - a.cu_k[b], nfull = lk / KBG;
+    if (kb < nfull) bwd1p_body<false>(a, dq32, lds, b, h, kb * KBG);
+    else if (kb == nfull && lk > nfull * KBG) bwd1p_body<true>(a, dq32, lds, b, h, nfull * KBG);
+}
+
 }  // namespace
 
-size_t acai_attn_bwd1p_workspace(int total_q, int H) { return (size_t)total_q * H * 32 * sizeof(float); }
+// (64 rows more than the gradient: a workgroup's first two tiles "add" the zero-filled partial sets to the sequence's first 64 rows without a range
+// check - for a sequence shorter than that, or the last one, those adds of 0.0 land in the next sequence's rows or in the padding)
+size_t acai_attn_bwd1p_workspace(int total_q, int H) { return ((size_t)total_q + 64) * H * 32 * sizeof(float); }
 
-void acai_attn_bwd1p_launch(const BwdArgs &a, int B, int max_k, void *workspace, hipStream_t st) {
+// partial_blocks: 0 = the host knows every sequence is a whole number of 512-key blocks (no slot for the keys past the last full block);
+// equal_len: the host knows all sequences have max_q queries and max_k keys (the XCD-aware block order)
+void acai_attn_bwd1p_launch(const BwdArgs &a, int B, int max_k, int partial_blocks, int equal_len, void *workspace, hipStream_t st) {
     BwdArgs w = a;
-    w.nblk = max_k / KBG;
+    w.nblk = max_k / KBG + (partial_blocks ? 1 : 0);
+    w.tail256 = equal_len ? 1 : 0;   // (this kernel's use of the field: the XCD-aware block order, for batches known to be equal-length)
     float *dq32 = reinterpret_cast<float *>(workspace);
     static bool attr[ACAI_MAX_DEV] = {};
     if (acai_first_on_device(attr))
         hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd1p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-    const int pairs4 = a.total_q * a.H * 4;
+    const int pairs4 = (a.total_q + 64) * a.H * 4;
     hipLaunchKernelGGL(bwd1p_delta_kernel, dim3(cdiv(pairs4, 256)), dim3(256), 0, st, w, dq32, a.total_q);
     hipLaunchKernelGGL(attn_bwd1p_kernel, dim3(w.nblk * a.H * B), dim3(NT), LDS_TOTAL, st, w, dq32);
-    hipLaunchKernelGGL(bwd1p_scale_kernel, dim3(cdiv(pairs4, 256)), dim3(256), 0, st, w, dq32, a.total_q);
+    hipLaunchKernelGGL(bwd1p_scale_kernel, dim3(cdiv(a.total_q * a.H * 4, 256)), dim3(256), 0, st, w, dq32, a.total_q);
 }

@@ -149,11 +149,11 @@ int acai_attn_varlen_bwd(const void *q, int ldq, const void *k, int ldk, const v
                          const void *dout, int lddo, void *dq, int lddq, void *dk, int lddk, void *dv, int lddv, const float *lse,
                          float *delta, const int32_t *cu_q, const int32_t *cu_k, int B, int H, int dh, int max_q, int max_k,
                          int total_q, int causal, int dtype, float dropout_p, uint32_t dropout_seed, int q_prescaled, void *stream);
-/* The same backward with a caller-lent device workspace (round 4).  With bf16, d_h = 32, q_prescaled, no dropout / mask / accumulation and every
- * sequence exactly max_k keys long (total_k = B * max_k, the rows of k / v; max_k % 512 == 0, max_q >= 512) - the MAE decoder's self-attention
- * (models.py:186-190) - dQ, dK and dV come from ONE pass over the scores (attn_bwd1p.hip): the key blocks add their part of a query's gradient
- * to the fp32 workspace with float atomics, so dQ is reproducible to fp32 rounding, not bit for bit (ACAI_ATTN_BWD_1P=0 in the environment, or
- * no workspace, keeps the two-kernel form, which is).  acai_attn_varlen_bwd_workspace_bytes: bytes that form needs for a call with these
+/* The same backward with a caller-lent device workspace (round 4).  With bf16, d_h = 32, q_prescaled, no dropout / mask / accumulation and
+ * max_q, max_k >= 512 - the MAE decoder's self-attention (models.py:186-190), ragged batches included - dQ, dK and dV come from ONE pass over
+ * the scores (attn_bwd1p.hip): the key blocks add their part of a query's gradient to the fp32 workspace with float atomics, so dQ is
+ * reproducible to fp32 rounding, not bit for bit (ACAI_ATTN_BWD_1P=0 in the environment, or no workspace, keeps the two-kernel form, which
+ * is).  total_k = the rows of k / v (0 = unknown: when it equals B * max_k with max_k % 512 == 0 the launch for partial key blocks is left out).  acai_attn_varlen_bwd_workspace_bytes: bytes that form needs for a call with these
  * arguments, 0 when it does not apply (then any workspace is ignored).  The workspace is used only inside the call (stream order). */
 size_t acai_attn_varlen_bwd_workspace_bytes(int B, int H, int dh, int max_q, int max_k, int total_q, int total_k, int causal, int dtype,
                                             float dropout_p, int q_prescaled);

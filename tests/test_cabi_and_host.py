@@ -179,24 +179,25 @@ def test_cu_seqlens_are_cached_per_lengths_and_uploads_pass_cpu_through():
 
 
 def test_attn_backward_workspace_query_matches_the_dispatch():
-    """acai_attn_varlen_bwd_workspace_bytes names the shapes the one-pass form takes: [total_q][H][32] fp32 for them, zero for the rest.  A host-side
-    function: no device is touched."""
+    """acai_attn_varlen_bwd_workspace_bytes names the calls the one-pass form takes: [total_q + 64][H][32] fp32 for them, zero for the rest.  A
+    host-side function: no device is touched."""
     from acai_omr_amd import _lib
     L = _lib.lib()
     bf, f32 = _lib.ACAI_BF16, _lib.ACAI_F32
     q = lambda *a: int(L.acai_attn_varlen_bwd_workspace_bytes(*a))
+    full = (16384 + 64) * 16 * 32 * 4
     #            B  H  dh  max_q max_k total_q total_k flags dtype p  pre
-    assert q(4, 16, 32, 4096, 4096, 16384, 16384, 0, bf, 0.0, 1) == 16384 * 16 * 32 * 4
+    assert q(4, 16, 32, 4096, 4096, 16384, 16384, 0, bf, 0.0, 1) == full
+    assert q(4, 16, 32, 4096, 4096, 16000, 16384, 0, bf, 0.0, 1) == (16000 + 64) * 16 * 32 * 4   # ragged queries
+    assert q(4, 16, 32, 4096, 4000, 16384, 15000, 0, bf, 0.0, 1) == full   # ragged keys, not a multiple of 512: the partial-block launch
     assert q(4, 16, 32, 4096, 4096, 16384, 16384, 0, bf, 0.0, 0) == 0      # q not prescaled
     assert q(4, 16, 32, 4096, 4096, 16384, 16384, 1, bf, 0.0, 1) == 0      # causal
     assert q(4, 16, 32, 4096, 4096, 16384, 16384, 2, bf, 0.0, 1) == 0      # accumulating dk / dv
     assert q(4, 16, 32, 4096, 4096, 16384, 16384, 0, bf, 0.1, 1) == 0      # dropout
     assert q(4, 16, 32, 4096, 4096, 16384, 16384, 0, f32, 0.0, 1) == 0     # fp32
     assert q(4, 16, 64, 4096, 4096, 16384, 16384, 0, bf, 0.0, 1) == 0      # d_h = 64
-    assert q(4, 16, 32, 4096, 4096, 16000, 16384, 0, bf, 0.0, 1) == 0      # ragged queries
-    assert q(4, 16, 32, 4096, 4096, 16384, 16000, 0, bf, 0.0, 1) == 0      # ragged keys
-    assert q(4, 16, 32, 4096, 4000, 16384, 16000, 0, bf, 0.0, 1) == 0      # keys not a multiple of 512
     assert q(4, 16, 32, 256, 512, 1024, 2048, 0, bf, 0.0, 1) == 0          # short query side: the two-kernel form
+    assert q(4, 16, 32, 512, 400, 2048, 1600, 0, bf, 0.0, 1) == 0          # short key side
 
 
 def test_asm_checks_flag_what_they_are_for():

@@ -69,6 +69,7 @@ def test_gemm_transposed_variants(dev, M, N, K, dtype):
     # fp64 autograd reference - square, a query count that ends inside a 64-row tile, more keys than queries
     (2, 32, [1024, 1024], None, False),
     (3, 32, [600, 600], [1536, 1536], False),
+    (2, 32, [700, 40, 1300], [1100, 300, 1025], False),      # ragged: partial key blocks, a short sequence, a one-key tail
 ])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("prescaled", [False, True])
@@ -169,15 +170,19 @@ import sys, torch
 from acai_omr_amd import engine, ops
 dev, bf, dh = "cuda", torch.bfloat16, 32
 out = {}
-for name, B, H, lq, lk in (("square", 3, 3, 1024, 1024), ("ragged_last_tile", 2, 2, 1000, 1536), ("smallest", 1, 1, 512, 512)):
+for name, H, lens_q, lens_k in (("square", 3, [1024] * 3, [1024] * 3), ("ragged_last_tile", 2, [1000] * 2, [1536] * 2), ("smallest", 1, [512], [512]),
+                               # ragged batches: keys past the last full 512-key block (the second launch), a sequence shorter than one block / one tile,
+                               # a one-key tail, a sequence whose keys are all tail, fewer than 64 queries in the LAST sequence (the workspace's padding rows)
+                               ("ragged", 2, [700, 40, 1300, 513], [1100, 300, 1025, 512]), ("ragged_short_last", 1, [600, 33], [640, 511])):
     E = H * dh
-    g = torch.Generator().manual_seed(lq + lk)
-    qkv = torch.randn(B * lk, 3 * E, generator=g).to(dev).to(bf)          # k, v: strided views of one buffer, like the in-projection's output
-    q = (torch.randn(B * lq, E, generator=g) * ops.QSCALE(dh)).to(dev).to(bf)
+    B, lq, lk = len(lens_q), max(lens_q), max(lens_k)
+    g = torch.Generator().manual_seed(sum(lens_q) + sum(lens_k))
+    qkv = torch.randn(sum(lens_k), 3 * E, generator=g).to(dev).to(bf)     # k, v: strided views of one buffer, like the in-projection's output
+    q = (torch.randn(sum(lens_q), E, generator=g) * ops.QSCALE(dh)).to(dev).to(bf)
     k, v = qkv[:, E:2 * E], qkv[:, 2 * E:]
-    do = torch.randn(B * lq, E, generator=g).to(dev).to(bf)
-    cu_q, cu_k = engine.cu_from_lens([lq] * B, dev), engine.cu_from_lens([lk] * B, dev)
-    lse = torch.empty(H * B * lq, device=dev)
+    do = torch.randn(sum(lens_q), E, generator=g).to(dev).to(bf)
+    cu_q, cu_k = engine.cu_from_lens(lens_q, dev), engine.cu_from_lens(lens_k, dev)
+    lse = torch.empty(H * sum(lens_q), device=dev)
     o = ops.attn_varlen(q, k, v, cu_q, cu_k, H, dh, lq, lse=lse, q_prescaled=True)
     dq, dkv = torch.full_like(q, 7.0), torch.full_like(qkv, 7.0)
     for rep in range(2):   # (twice: the workspace is reused and must be re-zeroed by the call itself)
@@ -189,10 +194,11 @@ torch.save(out, sys.argv[1])
 
 
 def test_attn_backward_one_pass_dh32_equals_the_two_kernel_form(dev, tmp_path):
-    """attn_bwd1p.hip (bf16, d_h = 32, prescaled q, equal-length sequences of a multiple of 512 keys): P and dS are formed once per score and
-    dQ is summed over the key blocks with fp32 atomics, so against the two-kernel form (ACAI_ATTN_BWD_1P=0) dK / dV agree to the last place
-    and dQ to the rounding of an fp32 sum taken in another order.  Query counts that end inside a 64-row tile, strided k / v / dk / dv views,
-    the smallest shape the form takes, and a second call over the same workspace.  The form is chosen once per process: child processes."""
+    """attn_bwd1p.hip (bf16, d_h = 32, prescaled q, no mask, long sequences): P and dS are formed once per score and dQ is summed over the
+    key blocks with fp32 atomics, so against the two-kernel form (ACAI_ATTN_BWD_1P=0) dK / dV agree to the last place and dQ to the rounding
+    of an fp32 sum taken in another order.  Query counts that end inside a 64-row tile, strided k / v / dk / dv views, the smallest shape
+    the form takes, ragged batches (partial key blocks, short sequences), and a second call over the same workspace.  The form is chosen
+    once per process: child processes."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
