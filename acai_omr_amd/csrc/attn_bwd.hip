@@ -1004,7 +1004,7 @@ int launch_bwd(const BwdArgs &a, int B, int max_q, int max_k, bool pre, void *ws
                     const int rows = wq ? (eq_q ? max_q % 256 : 255) : max_q;
                     hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DHP, F, D, P>), dim3(cdiv(rows, OB), a.H, B), dim3(256), lds_dq, st, t);
                 }
-                if (wk) acai_attn_bwd64w_dkv_launch(a, B, max_k, st);
+                if (wk) acai_attn_bwd64w_dkv_launch(a, B, max_k, eq_k ? 1 : 0, st);
                 if (!wk || !eq_k || max_k % 256) {
                     t.tail256 = wk ? 2 : 0;
                     const int rows = wk ? (eq_k ? max_k % 256 : 255) : max_k;

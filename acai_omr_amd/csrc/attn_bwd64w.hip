@@ -159,10 +159,10 @@ typedef std::true_type Y;
 typedef std::false_type N;
 
 // XCD-aware block order of a one-dimensional grid (see attn_fwd64w.hip): the blocks of one (sequence, head) stream the same operand tiles
-__device__ __forceinline__ int xcd_vid() {
+__device__ __forceinline__ int xcd_vid(bool xcd) {   // (xcd = false: a ragged batch keeps the plain order, see attn_bwd1p.hip)
     int vid = blockIdx.x;
     const int per = gridDim.x >> 3;
-    if (vid < (per << 3)) vid = (vid & 7) * per + (vid >> 3);
+    if (xcd && vid < (per << 3)) vid = (vid & 7) * per + (vid >> 3);
     return vid;
 }
 
@@ -209,8 +209,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     __shared__ __attribute__((aligned(16))) unsigned char lds[6 * SLOT];   // K ring: slots 0..2; V ring: slots 3..5
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
-    const int vid = xcd_vid();
-    const int qb = vid % a.nblk, h = (vid / a.nblk) % a.H, b = vid / (a.nblk * a.H);
+    const int vid = xcd_vid(a.nblk > 0), nblk = a.nblk < 0 ? -a.nblk : a.nblk;
+    const int qb = vid % nblk, h = (vid / nblk) % a.H, b = vid / (nblk * a.H);
     const int q_start = a.cu_q[b], lq = a.cu_q[b + 1] - q_start;
     const int k_start = a.cu_k[b], lk = a.cu_k[b + 1] - k_start;
     const int q0 = qb * RBG;
@@ -439,8 +439,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * QSLOT];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
-    const int vid = xcd_vid();
-    const int kb = vid % a.nblk, h = (vid / a.nblk) % a.H, b = vid / (a.nblk * a.H);
+    const int vid = xcd_vid(a.nblk > 0), nblk = a.nblk < 0 ? -a.nblk : a.nblk;
+    const int kb = vid % nblk, h = (vid / nblk) % a.H, b = vid / (nblk * a.H);
     const int q_start = a.cu_q[b], lq = a.cu_q[b + 1] - q_start;
     const int k_start = a.cu_k[b], lk = a.cu_k[b + 1] - k_start;
     const int k0 = kb * RBG;
@@ -704,11 +704,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 void acai_attn_bwd64w_dq_launch(const BwdArgs &a, int B, int max_q, hipStream_t st) {
     BwdArgs w = a;
     w.nblk = max_q / RBG;
-    if (w.nblk > 0) hipLaunchKernelGGL(attn_bwd64w_dq_kernel, dim3(w.nblk * a.H * B), dim3(NT), 0, st, w);
+    const int grid = w.nblk * a.H * B;
+    if (!acai_xcd_order((long long)B * max_q == (long long)a.total_q)) w.nblk = -w.nblk;   // (nblk < 0: plain block order)
+    if (grid > 0) hipLaunchKernelGGL(attn_bwd64w_dq_kernel, dim3(grid), dim3(NT), 0, st, w);
 }
 
-void acai_attn_bwd64w_dkv_launch(const BwdArgs &a, int B, int max_k, hipStream_t st) {
+void acai_attn_bwd64w_dkv_launch(const BwdArgs &a, int B, int max_k, int equal_len, hipStream_t st) {
     BwdArgs w = a;
     w.nblk = max_k / RBG;
-    if (w.nblk > 0) hipLaunchKernelGGL(attn_bwd64w_dkv_kernel, dim3(w.nblk * a.H * B), dim3(NT), 0, st, w);
+    const int grid = w.nblk * a.H * B;
+    if (!acai_xcd_order(equal_len != 0)) w.nblk = -w.nblk;
+    if (grid > 0) hipLaunchKernelGGL(attn_bwd64w_dkv_kernel, dim3(grid), dim3(NT), 0, st, w);
 }

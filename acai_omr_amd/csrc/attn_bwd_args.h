@@ -20,7 +20,7 @@ struct BwdArgs {
 // bf16, d_h = 64 exactly, q prescaled, no dropout, no causal mask, 16-byte aligned operands: the full 256-query blocks of dQ (which also
 // publishes -delta for every row of those blocks) and the full 256-key blocks of dK / dV (attn_bwd64w.hip)
 void acai_attn_bwd64w_dq_launch(const BwdArgs &a, int B, int max_q, hipStream_t st);
-void acai_attn_bwd64w_dkv_launch(const BwdArgs &a, int B, int max_k, hipStream_t st);
+void acai_attn_bwd64w_dkv_launch(const BwdArgs &a, int B, int max_k, int equal_len, hipStream_t st);   // equal_len: every sequence has max_k keys (XCD-aware block order)
 
 // bf16, d_h = 32 exactly, q prescaled, no dropout, no causal mask, no accumulation, aligned operands: dQ, dK, dV in one pass over the scores
 // (attn_bwd1p.hip; a sequence's full 512-key blocks in one launch, the keys past them - partial_blocks != 0 - in a second).  workspace:

@@ -58,12 +58,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // stream the same K / V (1 MB at 4096 keys): with (block, head, sequence) taken straight from the id, every XCD's 4 MB L2 saw the K / V of all
     // ~16 pairs in flight and served the tiles from the Infinity Cache.  Ids congruent mod 8 (one XCD, dispatched together) get a contiguous run of
     // virtual ids instead, so a pair's blocks share one L2.  (Placement is a speed matter only.)
+    // nqb < 0: a RAGGED batch, plain order - the static split leaves the XCD with the longest sequences working alone at the end (attn_bwd1p.hip).
     int vid = blockIdx.x;
-    {
+    const int nqb = a.nqb < 0 ? -a.nqb : a.nqb;
+    if (a.nqb > 0) {
         const int per = gridDim.x >> 3;
         if (vid < (per << 3)) vid = (vid & 7) * per + (vid >> 3);
     }
-    const int qb = vid % a.nqb, h = (vid / a.nqb) % a.H, b = vid / (a.nqb * a.H);
+    const int qb = vid % nqb, h = (vid / nqb) % a.H, b = vid / (nqb * a.H);
     const int q_start = a.cu_q[b], lq = a.cu_q[b + 1] - q_start;
     const int k_start = a.cu_k[b], lk = a.cu_k[b + 1] - k_start;
     const int q0 = qb * QBG;
@@ -400,14 +402,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 void acai_attn_fwd64w_launch(const AttnArgs &a, int B, int max_q, hipStream_t st) {
     AttnArgs w = a;
     w.nqb = cdiv(max_q, QBG);
+    const int grid = w.nqb * a.H * B;
+    if (!acai_xcd_order((long long)B * max_q == (long long)a.total_q)) w.nqb = -w.nqb;
 #ifdef ACAI_ATTN64_ABLATE
     const int abl = getenv("ACAI_ATTN64_ABL") ? atoi(getenv("ACAI_ATTN64_ABL")) : 0;
-#define ACAI_ABL_CASE(X) case X: hipLaunchKernelGGL(attn_fwd64w_kernel<X>, dim3(w.nqb * a.H * B), dim3(NT), 0, st, w); return;
+#define ACAI_ABL_CASE(X) case X: hipLaunchKernelGGL(attn_fwd64w_kernel<X>, dim3(grid), dim3(NT), 0, st, w); return;
     switch (abl) {
         ACAI_ABL_CASE(1) ACAI_ABL_CASE(3) ACAI_ABL_CASE(4) ACAI_ABL_CASE(8) ACAI_ABL_CASE(12) ACAI_ABL_CASE(16) ACAI_ABL_CASE(32) ACAI_ABL_CASE(48)
         ACAI_ABL_CASE(64) ACAI_ABL_CASE(15) ACAI_ABL_CASE(79) ACAI_ABL_CASE(112) ACAI_ABL_CASE(124) ACAI_ABL_CASE(7) ACAI_ABL_CASE(120) ACAI_ABL_CASE(76) ACAI_ABL_CASE(128) ACAI_ABL_CASE(256) ACAI_ABL_CASE(512) ACAI_ABL_CASE(384) ACAI_ABL_CASE(640) ACAI_ABL_CASE(768) ACAI_ABL_CASE(896)
         default: break;
     }
 #endif
-    hipLaunchKernelGGL(attn_fwd64w_kernel<0>, dim3(w.nqb * a.H * B), dim3(NT), 0, st, w);
+    hipLaunchKernelGGL(attn_fwd64w_kernel<0>, dim3(grid), dim3(NT), 0, st, w);
 }

@@ -170,6 +170,13 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // Once-per-DEVICE latch for hipFuncSetAttribute and the like (function attributes are per device; a per-process `static bool` skipped the
 // call for every device after the first when one process drives several GPUs).  Usage: static bool seen[ACAI_MAX_DEV]; if (acai_first_on_device(seen)) ...
 constexpr int ACAI_MAX_DEV = 64;
+// XCD-aware block order of the one-dimensional attention grids: on for batches the host knows to be equal-length, off for ragged ones (the static
+// split of the (sequence, head) pairs over the XCDs leaves the one with the longest sequences working alone at the end: attn_bwd1p.hip has the
+// measurement).  ACAI_XCD_ORDER=0 / 1 forces it off / on (A/B aid, read once).
+static inline bool acai_xcd_order(bool equal_len) {
+    static const int force = getenv("ACAI_XCD_ORDER") ? atoi(getenv("ACAI_XCD_ORDER")) : -1;
+    return force < 0 ? equal_len : force != 0;
+}
 static inline bool acai_first_on_device(bool (&seen)[ACAI_MAX_DEV]) {
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= ACAI_MAX_DEV) return true;   // unknown device: just do the (idempotent) call

@@ -1,11 +1,13 @@
-"""The d_h = 32 attention backward on a RAGGED batch shaped like config 5's MAE decoder stream (images 256x1024 ... 768x3072 -> 1024 ... 9216
-tokens): python tools/bench_attn_ragged.py   (ACAI_ATTN_BWD_1P=0: the two-kernel form)"""
+"""Attention forward / backward on a RAGGED batch shaped like config 5's streams (images 256x1024 ... 768x3072 -> 1024 ... 9216 tokens):
+python tools/bench_attn_ragged.py [H dh]   (default 16 32: the MAE decoder; 12 64: the encoder.  ACAI_ATTN_BWD_1P=0: the two-kernel d_h = 32
+backward; ACAI_XCD_ORDER=0 / 1: the XCD-aware block order of the one-dimensional grids forced off / on)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from acai_omr_amd import engine, ops
 
-dev, bf, H, dh = torch.device("cuda", 0), torch.bfloat16, 16, 32
+dev, bf = torch.device("cuda", 0), torch.bfloat16
+H, dh = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (16, 32)
 E = H * dh
 g = torch.Generator().manual_seed(0)
 sizes = [(256, 1024), (384, 1536), (512, 2048), (640, 2560), (768, 3072), (320, 1200), (448, 1808), (560, 2240)]
@@ -19,13 +21,16 @@ lse = torch.empty(H * tot, device=dev)
 o = ops.attn_varlen(q, k, v, cu, cu, H, dh, max(lens), lse=lse, q_prescaled=True)
 d = torch.empty_like(qkv)
 bwd = lambda: ops.attn_varlen_bwd(q, k, v, o, dout, lse, cu, cu, H, dh, max(lens), max(lens), False, d[:, :E], d[:, E:2 * E], d[:, 2 * E:], q_prescaled=True)
-bwd()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(10):
-    bwd()
-torch.cuda.synchronize()
-ms = (time.perf_counter() - t0) / 10 * 1e3
+fwd = lambda: ops.attn_varlen(q, k, v, cu, cu, H, dh, max(lens), lse=lse, q_prescaled=True)
+res = {}
+for name, fn in (("fwd", fwd), ("bwd", bwd)):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    res[name] = (time.perf_counter() - t0) / 10 * 1e3
 scores = H * sum(l * l for l in lens)
-print(f"ragged batch of {len(lens)} sequences ({min(lens)}..{max(lens)} tokens, {tot} in all): bwd {ms:.3f} ms ({scores / ms / 1e9:.2f} T scores/s)  "
-      f"[ACAI_ATTN_BWD_1P={os.environ.get('ACAI_ATTN_BWD_1P', '1')}]")
+print(f"ragged batch of {len(lens)} sequences ({min(lens)}..{max(lens)} tokens, {tot} in all), {H} heads of {dh}: fwd {res['fwd']:.3f} ms  bwd {res['bwd']:.3f} ms "
+      f"({scores / res['bwd'] / 1e9:.2f} T scores/s)  [ACAI_ATTN_BWD_1P={os.environ.get('ACAI_ATTN_BWD_1P', '1')} ACAI_XCD_ORDER={os.environ.get('ACAI_XCD_ORDER', 'auto')}]")
