@@ -6,19 +6,22 @@
 // computes P and dS ONCE per score with the key on the lane - dK / dV accumulate in registers - and forms the query gradient from the same dS:
 //     dQ^T[d][q] += K^T[d][key] dS^T[key][q]
 // whose contraction runs over the lane dimension: dS crosses LDS once (the wave writes the [key][q] image of its own 32 keys and reads it back with the
-// transposing fragment read as the MFMA's B operand; K^T comes the same way from an LDS image of the workgroup's K rows), and a query's gradient is a
-// sum over the workgroups that own its keys: the four waves of a workgroup (512 keys) add their partial tiles in LDS and the workgroup adds the result
-// to an fp32 buffer with no-return float atomics, 128 contiguous bytes per query row and 32 lanes (MI355X_MICROARCH.md "Global float atomics": ~1.3 TB/s
-// chip-wide; 4096 keys / 512 = 8 adds per element: 2.1 GB per MAE decoder layer = 1.65 ms at that rate, under the kernel's time).  A first small kernel
-// forms delta and zeroes that buffer, a last one scales it into the bf16 gradient.  The sum over key blocks is in arrival order: dQ is reproducible
-// to fp32 rounding, not bit for bit (ACAI_ATTN_BWD_1P=0 keeps the two-pass kernels, which are).
+// transposing fragment read as the MFMA's B operand; the K^T fragments are read the same way, once, from a prologue image of the wave's K rows, and
+// stay in registers), and a query's gradient is a sum over the workgroups that own its keys: the four waves of a workgroup (512 keys) add their
+// partial tiles in LDS and the workgroup adds the result to an fp32 buffer with no-return float atomics, 128 contiguous bytes per query row and 32
+// lanes (measured 1.35 TB/s chip-wide, profiles/r04_atomic_rate.txt; 4096 keys / 512 = 8 adds per element: 2.15 GB per MAE decoder layer = 1.58 ms of
+// atomic-unit time, inside the kernel's 2.9 ms).  A first small kernel forms delta and zeroes that buffer, a last one scales it into the bf16 gradient.
+// The sum over key blocks is in arrival order: dQ is reproducible to fp32 rounding, not bit for bit (ACAI_ATTN_BWD_1P=0 keeps the two-pass kernels,
+// which are).  Measured: 32 x 16 heads x 4096^2 3.00 ms against 3.78 for the two kernels; DESIGN.md section 5 has the counters and ablations.
 //
-// One wave per SIMD, four lane-owned 32-key blocks per wave: dK / dV 128 accumulator registers, the K / V fragments (B operands of S and dP) 64 more,
-// pinned there by inline-asm MFMAs (file built with -mllvm -amdgpu-mfma-vgpr-form), and a software pipeline over the work items w = (32-query block,
+// One wave per SIMD, four lane-owned 32-key blocks per wave: dK / dV 128 accumulator registers, the K / V fragments (B operands of S and dP) 64 and the
+// K^T fragments 32 more, pinned there by inline-asm MFMAs (file built with -mllvm -amdgpu-mfma-vgpr-form), and a software pipeline over the work items w = (32-query block,
 // owned block j): slot w issues the four S / dP MFMAs of item w+1 and the six gradient MFMAs of item w-1 (dV, dK, dQ) while the VALU turns item w's
 // scores into P and dS - 48 numbered single-issue operations dealt over the slot's ten MFMA gaps.  EVERY tile runs the same code (the first tile's
 // "previous item" multiplies zero packs): with first- / last-tile variants of the tile body the accumulator tuples met in register copies and
-// scratch round trips at every region boundary (hundreds of spills - what sank the first version of this kernel).
+// scratch round trips at every region boundary (hundreds of spills - what sank the first version of this kernel).  And since with one wave per SIMD
+// nothing issues beside the wave's own stream - every instruction of any kind is a four-cycle issue turn (profiles/r04_valu_issue.txt) - the steady
+// state carries no padding s_nop, no register copies and no address arithmetic that a rotating offset or a scalar operand can replace.
 #include "attn_bwd_args.h"
 
 #include <type_traits>
