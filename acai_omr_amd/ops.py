@@ -357,9 +357,11 @@ def _bwd_workspace(device, nbytes):
     return ws
 
 
-def attn_varlen_bwd(q, k, v, o, dout, lse, cu_q, cu_k, H, dh, max_q, max_k, causal, dq, dk, dv, dropout_p=0.0, seed=0, q_prescaled=False, accumulate_dkv=False):
+def attn_varlen_bwd(q, k, v, o, dout, lse, cu_q, cu_k, H, dh, max_q, max_k, causal, dq, dk, dv, dropout_p=0.0, seed=0, q_prescaled=False, accumulate_dkv=False,
+                    lend_workspace=True):
     """Gradients of attn_varlen w.r.t. q, k, v, written into the (strided) views dq, dk, dv.  q_prescaled: q is the forward's prescaled
-    q; dq is still the gradient w.r.t. the unscaled in-projection output.  accumulate_dkv: dk, dv += (bf16, aligned operands only)."""
+    q; dq is still the gradient w.r.t. the unscaled in-projection output.  accumulate_dkv: dk, dv += (bf16, aligned operands only).
+    lend_workspace=False: no workspace is offered, i.e. the two-kernel form whose dq is bit-reproducible (acai_attn_varlen_bwd_ws)."""
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (dout, "dout"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
         _chk(t, n)
         assert t.dim() == 2 and t.dtype == q.dtype, n
@@ -371,7 +373,7 @@ def attn_varlen_bwd(q, k, v, o, dout, lse, cu_q, cu_k, H, dh, max_q, max_k, caus
     flags = (1 if causal else 0) | (2 if accumulate_dkv else 0)
     total_k = k.shape[0]
     need = _lib.lib().acai_attn_varlen_bwd_workspace_bytes(B, H, dh, int(max_q), int(max_k), total_q, total_k, flags, _dt(q), float(dropout_p), 1 if q_prescaled else 0)
-    ws = _bwd_workspace(q.device, need) if need else None
+    ws = _bwd_workspace(q.device, need) if need and lend_workspace else None
     _lib.check(_lib.lib().acai_attn_varlen_bwd_ws(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), o.data_ptr(), o.stride(0),
                                                   dout.data_ptr(), dout.stride(0), dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(),
                                                   dv.stride(0), lse.data_ptr(), delta.data_ptr(), cu_q.data_ptr(), cu_k.data_ptr(), B, H, dh, int(max_q),

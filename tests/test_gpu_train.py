@@ -221,6 +221,43 @@ def test_attn_backward_one_pass_dh32_equals_the_two_kernel_form(dev, tmp_path):
                 assert float((d > 0).float().mean()) < 1e-3, (case, float((d > 0).float().mean()))
 
 
+def test_attn_backward_one_pass_random_ragged_batches(dev):
+    """The one-pass d_h = 32 backward against the two-kernel form (the second call lends no workspace) on randomly drawn ragged self- and
+    cross-attention batches: sequences shorter than a tile, lengths on and next to the 512-key block edges, up to five sequences and four
+    heads (tools/stress_bwd1p.py draws more of the same)."""
+    import random
+    from acai_omr_amd import engine, ops
+    rng = random.Random(7)
+    bf, dh = torch.bfloat16, 32
+    for c in range(14):
+        B, H = rng.randint(1, 5), rng.randint(1, 4)
+        pick = lambda: rng.choice([rng.randint(1, 80), rng.randint(400, 700), 512, 513, 1024, rng.randint(900, 2100), 511, 64, 1536])
+        lens_q = [pick() for _ in range(B)]
+        lens_q[rng.randrange(B)] = rng.choice([512, 600, 1200])
+        lens_k = list(lens_q)
+        if c % 3 == 2:
+            lens_k = [pick() for _ in range(B)]
+            lens_k[rng.randrange(B)] = rng.choice([512, 700, 1536, 2049])
+        E = H * dh
+        g = torch.Generator().manual_seed(100 + c)
+        q = (torch.randn(sum(lens_q), E, generator=g) * ops.QSCALE(dh)).to(dev).to(bf)
+        kv = torch.randn(sum(lens_k), 2 * E, generator=g).to(dev).to(bf)
+        k, v = kv[:, :E], kv[:, E:]
+        do = torch.randn(sum(lens_q), E, generator=g).to(dev).to(bf)
+        cu_q, cu_k = engine.cu_from_lens(lens_q, dev), engine.cu_from_lens(lens_k, dev)
+        lse = torch.empty(H * sum(lens_q), device=dev)
+        o = ops.attn_varlen(q, k, v, cu_q, cu_k, H, dh, max(lens_q), lse=lse, q_prescaled=True)
+        outs = []
+        for lend in (True, False):
+            dq, dkv = torch.full_like(q, 7.0), torch.full_like(kv, 7.0)
+            ops.attn_varlen_bwd(q, k, v, o, do, lse, cu_q, cu_k, H, dh, max(lens_q), max(lens_k), False, dq, dkv[:, :E], dkv[:, E:], q_prescaled=True,
+                                lend_workspace=lend)
+            outs.append((dq.float().cpu(), dkv.float().cpu()))
+        for name, a, b in (("dq", outs[1][0], outs[0][0]), ("dkv", outs[1][1], outs[0][1])):
+            assert int(((b == 7.0) & (a != 7.0)).sum()) == 0, (c, name, "rows left at the fill value", lens_q, lens_k)
+            assert float((a - b).abs().max()) <= 2.0 ** -7 * max(1e-6, float(a.abs().max())), (c, name, B, H, lens_q, lens_k)
+
+
 @pytest.mark.parametrize("H,dh,S,B", [(16, 32, 4096, 2), (12, 64, 4096, 1)])
 def test_attn_prescaled_at_benchmark_size(dev, H, dh, S, B):
     """The attention kernels at the benchmarked sequence length (MAE decoder: 4096 tokens, 16 heads of 32; encoder: 12 heads of 64), bf16,
