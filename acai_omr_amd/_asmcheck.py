@@ -32,7 +32,8 @@ def _regs_of(text):
 
 
 def _functions(src, pattern):
-    for m in re.finditer(r"^(" + pattern + r"\w*):[^\n]*\n(.*?)s_endpgm", src, re.S | re.M):
+    # (up to the function's end label, not its first s_endpgm: an early return has its own)
+    for m in re.finditer(r"^(" + pattern + r"\w*):[^\n]*\n(.*?)^\.Lfunc_end\d+:", src, re.S | re.M):
         yield m.group(1), m.group(2).split("\n")
 
 

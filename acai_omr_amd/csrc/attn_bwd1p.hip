@@ -95,15 +95,15 @@ __device__ __forceinline__ void mma_ab(f32x16 &d, const uint4 &a, const u32x4 &b
 }
 
 // The VALU stream of one work item as 48 numbered single-issue operations (attn_bwd64w.hip: dkv_op):
-//   e(i): s[i] = P = 2^s[i] (MASK: 0 unless the query row - and, in the partial-block kernel, the lane's key - exists); m(i): p[i] = dS = s[i] p[i]; kP(n) / kS(n): bf16 pairs of P / dS
+//   e(i): s[i] = P = 2^s[i] (MASK: 0 unless the query row exists); m(i): p[i] = dS = s[i] p[i]; kP(n) / kS(n): bf16 pairs of P / dS
 //   e0 e1 | e2 e3 m0 m1 kP0 kS0 | ... | e14 e15 m12 m13 kP6 kS6 | m14 m15 kP7 kS7
-template <int OP, bool MASK>
-__device__ __forceinline__ void e_op(f32x16 &s, f32x16 &p, uint32_t (&xp)[8], uint32_t (&xs)[8], int row0, int lh, int rows, bool kok) {
+template <int OP, bool MASK, bool KMSK>
+__device__ __forceinline__ void e_op(f32x16 &s, f32x16 &p, uint32_t (&xp)[8], uint32_t (&xs)[8], int row0, int lh, int rows, uint32_t km) {
     constexpr int r = OP - 2, step = OP < 2 ? 0 : 1 + r / 6, w = OP < 2 ? OP : r % 6;
     if constexpr (step == 0 || (step < 8 && w < 2)) {
         constexpr int i = 2 * step + w;
         float v = fast_exp2(s[i]);
-        if constexpr (MASK) v = ((row0 + (i & 3) + 8 * (i >> 2) + 4 * lh) < rows && kok) ? v : 0.f;
+        if constexpr (MASK) v = (row0 + (i & 3) + 8 * (i >> 2) + 4 * lh) < rows ? v : 0.f;
         s[i] = v;
     } else if constexpr (step < 8 ? w < 4 : w < 2) {
         constexpr int i = 2 * (step - 1) + (step < 8 ? w - 2 : w);
@@ -111,24 +111,26 @@ __device__ __forceinline__ void e_op(f32x16 &s, f32x16 &p, uint32_t (&xp)[8], ui
     } else if constexpr (step < 8 ? w == 4 : w == 2) {
         constexpr int n = step - 1;
         xp[n] = pack_bf16(s[2 * n], s[2 * n + 1]);
+        if constexpr (KMSK) xp[n] &= km;   // (the partial-block body: a lane whose key does not exist contributes P = 0 and dS = 0)
     } else {
         constexpr int n = step - 1;
         xs[n] = pack_bf16(p[2 * n], p[2 * n + 1]);
+        if constexpr (KMSK) xs[n] &= km;
     }
 }
-template <int OP, int END, bool MASK>
-__device__ __forceinline__ void e_ops(f32x16 &s, f32x16 &p, uint32_t (&xp)[8], uint32_t (&xs)[8], int row0, int lh, int rows, bool kok) {
+template <int OP, int END, bool MASK, bool KMSK>
+__device__ __forceinline__ void e_ops(f32x16 &s, f32x16 &p, uint32_t (&xp)[8], uint32_t (&xs)[8], int row0, int lh, int rows, uint32_t km) {
     if constexpr (OP < END) {
-        e_op<OP, MASK>(s, p, xp, xs, row0, lh, rows, kok);
-        e_ops<OP + 1, END, MASK>(s, p, xp, xs, row0, lh, rows, kok);
+        e_op<OP, MASK, KMSK>(s, p, xp, xs, row0, lh, rows, km);
+        e_ops<OP + 1, END, MASK, KMSK>(s, p, xp, xs, row0, lh, rows, km);
     }
 }
 // operations of MFMA gap G of a slot, dealt by issue TIME (an exp2 holds the issue port 8 cycles, the rest 4; an MFMA wants its predecessor 32 cycles
 // back): 3 3 4 5 5 5 5 5 6 7 - the first gaps also carry the slot's LDS instructions, the last ones nothing else
-template <int G, bool MASK>
-__device__ __forceinline__ void e_gap(f32x16 &s, f32x16 &p, uint32_t (&xp)[8], uint32_t (&xs)[8], int row0, int lh, int rows, bool kok) {
+template <int G, bool MASK, bool KMSK>
+__device__ __forceinline__ void e_gap(f32x16 &s, f32x16 &p, uint32_t (&xp)[8], uint32_t (&xs)[8], int row0, int lh, int rows, uint32_t km) {
     constexpr int start[11] = {0, 3, 6, 10, 15, 20, 25, 30, 35, 41, 48};
-    e_ops<start[G], start[G + 1], MASK>(s, p, xp, xs, row0, lh, rows, kok);
+    e_ops<start[G], start[G + 1], MASK, KMSK>(s, p, xp, xs, row0, lh, rows, km);
 }
 
 __device__ __forceinline__ uint4 x4(const uint32_t (&x)[8], int h) { return make_uint4(x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]); }
@@ -178,8 +180,8 @@ __global__ __launch_bounds__(256) void bwd1p_scale_kernel(BwdArgs a, const float
 }
 
 // One workgroup's work: 512 keys (k0 ...) of sequence b, head h.  KM = false: a FULL block.  KM = true: the keys past a sequence's last full block -
-// lanes whose key does not exist read the last key's row and are masked out of P in every tile; this instantiation runs the masked tile body only,
-// so each body still has ONE steady-state tile variant (see the header).
+// lanes whose key does not exist read the last key's row and their P / dS packs are ANDed to zero (16 more VALU operations per item; the unmasked
+// values never leave the lane's registers).
 template <bool KM>
 __device__ __forceinline__ void bwd1p_body(const BwdArgs &a, float *dq32, unsigned char *lds, int b, int h, int k0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -359,7 +361,7 @@ __device__ __forceinline__ void bwd1p_body(const BwdArgs &a, float *dq32, unsign
         constexpr int pE = decltype(pE_)::value, jA = decltype(jA_)::value, jC = decltype(jC_)::value;
         constexpr bool NP = M || !HE || !HA || !HC;
    // outside the steady-state loop the compiler's tuple copies at region edges may sit in front of an MFMA: pad
-        const bool kokE = !KM || ((kmask >> ((jA + 3) & 3)) & 1);   // item w's owned block is the one before A's
+        const uint32_t kmE = KM ? 0u - ((kmask >> ((jA + 3) & 3)) & 1u) : ~0u;   // all ones unless the lane's key of item w's owned block (the one before A's) does not exist
         f32x16 &sE = sc[pE], &pEd = dp[pE], &sA = sc[pE ^ 1], &pA = dp[pE ^ 1];
         uint32_t(&xpE)[8] = xp[pE], (&xsE)[8] = xs[pE], (&xpC)[8] = xp[pE ^ 1], (&xsC)[8] = xs[pE ^ 1];
         unsigned char *dsimg = dsreg + (pE ^ 1) * (32 * PITCH);
@@ -385,7 +387,7 @@ __device__ __forceinline__ void bwd1p_body(const BwdArgs &a, float *dq32, unsign
         // dK product reads - q in the order 16 P + 8 gl + 4 lh + i at column 16 P + 8 lh + 4 gl + i (bits 2 and 3 swapped), which the flush undoes
         if constexpr (HA) mma_ab0<NP>(sA, qr[0], kf[jA][0], nl);
         ACAI_SB();
-        if constexpr (HE) e_gap<0, M>(sE, pEd, xpE, xsE, rowE, lh, lq, kokE);
+        if constexpr (HE) e_gap<0, M, KM>(sE, pEd, xpE, xsE, rowE, lh, lq, kmE);
         if constexpr (HC && !(ACAI_1P_ABL & 16)) *reinterpret_cast<uint4 *>(dsimg + dsw[1]) = x4(xsC, 1);
         if constexpr (LOADROW) qr[0] = read_r(rowp, 0);
         red(I<0>{});
@@ -393,7 +395,7 @@ __device__ __forceinline__ void bwd1p_body(const BwdArgs &a, float *dq32, unsign
         // gap 1: C, dV k-step 0
         if constexpr (HC) mma_acc<NP>(dv[jC], dot[0].u, x4(xpC, 0));
         ACAI_SB();
-        if constexpr (HE) e_gap<1, M>(sE, pEd, xpE, xsE, rowE, lh, lq, kokE);
+        if constexpr (HE) e_gap<1, M, KM>(sE, pEd, xpE, xsE, rowE, lh, lq, kmE);
         if constexpr (HC && !(ACAI_1P_ABL & 16)) dst[0] = read_td(dsimg, 0);
         if constexpr (HC && (ACAI_1P_ABL & 16)) dst[0].u = make_uint4(xsC[0], xsC[1], xsC[2], xsC[3]);
         if constexpr (LOADROW) {
@@ -407,7 +409,7 @@ __device__ __forceinline__ void bwd1p_body(const BwdArgs &a, float *dq32, unsign
         // gap 2: A, dP k-step 0
         if constexpr (HA) mma_ab0<NP>(pA, dor[0], vf[jA][0], nd);
         ACAI_SB();
-        if constexpr (HE) e_gap<2, M>(sE, pEd, xpE, xsE, rowE, lh, lq, kokE);
+        if constexpr (HE) e_gap<2, M, KM>(sE, pEd, xpE, xsE, rowE, lh, lq, kmE);
         if constexpr (HC && !(ACAI_1P_ABL & 16)) dst[1] = read_td(dsimg, 1);
         if constexpr (HC && (ACAI_1P_ABL & 16)) dst[1].u = make_uint4(xsC[4], xsC[5], xsC[6], xsC[7]);
         if constexpr (LOADROW) dor[0] = read_r(rowp + TILE, 0);
@@ -417,7 +419,7 @@ __device__ __forceinline__ void bwd1p_body(const BwdArgs &a, float *dq32, unsign
         // gap 3: C, dV k-step 1
         if constexpr (HC) mma_acc<NP>(dv[jC], dot[1].u, x4(xpC, 1));
         ACAI_SB();
-        if constexpr (HE) e_gap<3, M>(sE, pEd, xpE, xsE, rowE, lh, lq, kokE);
+        if constexpr (HE) e_gap<3, M, KM>(sE, pEd, xpE, xsE, rowE, lh, lq, kmE);
         if constexpr (LOADROW) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4)
@@ -430,7 +432,7 @@ __device__ __forceinline__ void bwd1p_body(const BwdArgs &a, float *dq32, unsign
         // gap 4: A, S k-step 1
         if constexpr (HA) mma_ab<NP>(sA, qr[1], kf[jA][1]);
         ACAI_SB();
-        if constexpr (HE) e_gap<4, M>(sE, pEd, xpE, xsE, rowE, lh, lq, kokE);
+        if constexpr (HE) e_gap<4, M, KM>(sE, pEd, xpE, xsE, rowE, lh, lq, kmE);
         if constexpr (LOADROW) qr[1] = read_r(rowp, 1);
         if constexpr (FLUSH) flush_piece(pflush, 2);
         red(I<4>{});
@@ -438,7 +440,7 @@ __device__ __forceinline__ void bwd1p_body(const BwdArgs &a, float *dq32, unsign
         // gap 5: C, dK k-step 0
         if constexpr (HC) mma_acc<NP>(dk[jC], qt[0].u, x4(xsC, 0));
         ACAI_SB();
-        if constexpr (HE) e_gap<5, M>(sE, pEd, xpE, xsE, rowE, lh, lq, kokE);
+        if constexpr (HE) e_gap<5, M, KM>(sE, pEd, xpE, xsE, rowE, lh, lq, kmE);
         if constexpr (LOADT) qt[0] = read_t(tp, 0);
         if constexpr (FLUSH) flush_piece(pflush, 3);
         red(I<5>{});
@@ -446,7 +448,7 @@ __device__ __forceinline__ void bwd1p_body(const BwdArgs &a, float *dq32, unsign
         // gap 6: A, dP k-step 1
         if constexpr (HA) mma_ab<NP>(pA, dor[1], vf[jA][1]);
         ACAI_SB();
-        if constexpr (HE) e_gap<6, M>(sE, pEd, xpE, xsE, rowE, lh, lq, kokE);
+        if constexpr (HE) e_gap<6, M, KM>(sE, pEd, xpE, xsE, rowE, lh, lq, kmE);
         if constexpr (HE && !(ACAI_1P_ABL & 16)) *reinterpret_cast<uint4 *>(dsreg + pE * (32 * PITCH) + dsw[0]) = x4(xsE, 0);   // (its last pair is packed first thing in this gap)
         if constexpr (LOADROW) dor[1] = read_r(rowp + TILE, 1);
         red(I<6>{});
@@ -457,20 +459,20 @@ __device__ __forceinline__ void bwd1p_body(const BwdArgs &a, float *dq32, unsign
             else mma_acca<NP>(dqa, ktf[jC][0], dst[0].u);
         }
         ACAI_SB();
-        if constexpr (HE) e_gap<7, M>(sE, pEd, xpE, xsE, rowE, lh, lq, kokE);
+        if constexpr (HE) e_gap<7, M, KM>(sE, pEd, xpE, xsE, rowE, lh, lq, kmE);
         red(I<7>{});
         ACAI_SB();
         // gap 8: C, dK k-step 1 (between the two dQ k-steps: a dependent MFMA directly behind its producer waits for the whole pass)
         if constexpr (HC) mma_acc<NP>(dk[jC], qt[1].u, x4(xsC, 1));
         ACAI_SB();
-        if constexpr (HE) e_gap<8, M>(sE, pEd, xpE, xsE, rowE, lh, lq, kokE);
+        if constexpr (HE) e_gap<8, M, KM>(sE, pEd, xpE, xsE, rowE, lh, lq, kmE);
         if constexpr (LOADT) qt[1] = read_t(tp, 1);
         red(I<8>{});
         ACAI_SB();
         // gap 9: C, dQ k-step 1
         if constexpr (HC) mma_acca<NP>(dqa, ktf[jC][1], dst[1].u);
         ACAI_SB();
-        if constexpr (HE) e_gap<9, M>(sE, pEd, xpE, xsE, rowE, lh, lq, kokE);
+        if constexpr (HE) e_gap<9, M, KM>(sE, pEd, xpE, xsE, rowE, lh, lq, kmE);
         red(I<9>{});
         ACAI_SB();
     };
@@ -532,13 +534,9 @@ __device__ __forceinline__ void bwd1p_body(const BwdArgs &a, float *dq32, unsign
         // (the next tile's first query block is read during this tile's last slots and the next tile's first: it was stored during tile t-1 and
         // published by that tile's barrier; tile t+2 is stored in this tile's sixth slot into the slot tile t-1 left; past the last tile the ring holds
         // zeros - buffer loads beyond the end - and the extra A of the last slot feeds nothing)
-        if constexpr (KM) {
-            for (int t = 0; t < nqt; ++t) tile(Y{}, t);
-        } else {
-            int t = 0;
-            for (; t + 1 < nqt; ++t) tile(N{}, t);
-            tile(Y{}, t);   // the last tile: query rows past the end give probability zero
-        }
+        int t = 0;
+        for (; t + 1 < nqt; ++t) tile(N{}, t);
+        tile(Y{}, t);   // the last tile: query rows past the end give probability zero
         // ---- drain: C of the last item, the flush of the last query block, the last two tiles' sums (after the rotation: p2 = the last tile's set,
         // p1 = the one before) ---------------------------------------------------------------------------------------------------------------------
         slot(N{}, N{}, Y{}, N{}, N{}, N{}, N{}, I<0>{}, I<0>{}, I<0>{}, I<3>{}, 0, 0, 0, 0, 0, 0, 0);

@@ -206,17 +206,17 @@ def test_asm_checks_flag_what_they_are_for():
     tiles' stores than attn_fwd64w_kernel's counted tile barrier allows.  Doctored snippets: the clean form passes, the broken form is named."""
     from acai_omr_amd import _asmcheck
     head = "_ZN12_GLOBAL__N_117gemm_nt_pp_kernelItLi1EEEvNS_8GemmArgsE:\n"
-    clean = head + "\t;;#ASMSTART\n\tglobal_load_dword v7, v3, s[2:3]\n\t;;#ASMEND\n\tv_add_f32 v1, v2, v3\n\ts_waitcnt vmcnt(4)\n\tv_mov_b32 v9, v7\n\ts_endpgm\n"
-    broken = head + "\t;;#ASMSTART\n\tglobal_load_dword v7, v3, s[2:3]\n\t;;#ASMEND\n\tv_mov_b32 v9, v7\n\ts_waitcnt vmcnt(4)\n\ts_endpgm\n"
-    tracked = head + "\tglobal_load_dword v7, v3, s[2:3]\n\tv_mov_b32 v9, v7\n\ts_endpgm\n"     # a compiler-issued load: its own wait counts cover it
+    clean = head + "\t;;#ASMSTART\n\tglobal_load_dword v7, v3, s[2:3]\n\t;;#ASMEND\n\tv_add_f32 v1, v2, v3\n\ts_waitcnt vmcnt(4)\n\tv_mov_b32 v9, v7\n\ts_endpgm\n.Lfunc_end0:\n"
+    broken = head + "\t;;#ASMSTART\n\tglobal_load_dword v7, v3, s[2:3]\n\t;;#ASMEND\n\tv_mov_b32 v9, v7\n\ts_waitcnt vmcnt(4)\n\ts_endpgm\n.Lfunc_end0:\n"
+    tracked = head + "\tglobal_load_dword v7, v3, s[2:3]\n\tv_mov_b32 v9, v7\n\ts_endpgm\n.Lfunc_end0:\n"     # a compiler-issued load: its own wait counts cover it
     assert _asmcheck.check_untracked_loads(clean) == ([], 1)
     p, n = _asmcheck.check_untracked_loads(broken)
     assert n == 1 and len(p) == 1 and "v_mov_b32 v9, v7" in p[0]
     assert _asmcheck.check_untracked_loads(tracked) == ([], 0)
     whead = "_ZN12_GLOBAL__N_118attn_fwd64w_kernelILi0EEEv8AttnArgs:\n"
     reads = "".join(f"\tds_read_b64_tr_b16 v[{2 * i}:{2 * i + 1}], v100\n" for i in range(4))
-    ok = whead + "\tds_write_b128 v1, v[2:5]\n" + reads + "\ts_waitcnt lgkmcnt(4)\n\ts_barrier\n\ts_endpgm\n"
-    bad = whead + "\tds_write_b128 v1, v[2:5]\n" + reads + "\tds_read_b128 v[20:23], v101\n\ts_waitcnt lgkmcnt(4)\n\ts_barrier\n\ts_endpgm\n"
+    ok = whead + "\tds_write_b128 v1, v[2:5]\n" + reads + "\ts_waitcnt lgkmcnt(4)\n\ts_barrier\n\ts_endpgm\n.Lfunc_end0:\n"
+    bad = whead + "\tds_write_b128 v1, v[2:5]\n" + reads + "\tds_read_b128 v[20:23], v101\n\ts_waitcnt lgkmcnt(4)\n\ts_barrier\n\ts_endpgm\n.Lfunc_end0:\n"
     assert _asmcheck.check_fwd64w_barrier(ok) == ([], 1)
     p, n = _asmcheck.check_fwd64w_barrier(bad)
     assert n == 1 and len(p) == 1 and "5 LDS operations" in p[0]
@@ -226,15 +226,18 @@ def test_asm_checks_flag_what_they_are_for():
     # an accumulate chain of MFMAs on the same C / D registers is legal back to back
     bhead = "_ZN12_GLOBAL__N_121attn_bwd64w_dq_kernelE7BwdArgs:\n"
     mf = "\tv_mfma_f32_32x32x16_bf16 a[32:47], a[72:75], v[92:95], a[32:47]\n"
-    hazard = bhead + "\tv_accvgpr_mov_b32 a75, a3\n\t;;#ASMSTART\n" + mf + "\t;;#ASMEND\n\ts_endpgm\n"
-    padded = bhead + "\tv_accvgpr_mov_b32 a75, a3\n\t;;#ASMSTART\n\ts_nop 1\n" + mf + "\t;;#ASMEND\n\ts_endpgm\n"
-    spaced = bhead + "\tv_cvt_pk_bf16_f32 v93, v1, v2\n\tv_exp_f32_e32 v7, v8\n\tds_read_b128 v[20:23], v101\n\t;;#ASMSTART\n" + mf + "\t;;#ASMEND\n\ts_endpgm\n"
-    chain = bhead + "\t;;#ASMSTART\n" + mf + "\t;;#ASMEND\n\t;;#ASMSTART\n" + mf + "\t;;#ASMEND\n\ts_endpgm\n"
+    hazard = bhead + "\tv_accvgpr_mov_b32 a75, a3\n\t;;#ASMSTART\n" + mf + "\t;;#ASMEND\n\ts_endpgm\n.Lfunc_end0:\n"
+    padded = bhead + "\tv_accvgpr_mov_b32 a75, a3\n\t;;#ASMSTART\n\ts_nop 1\n" + mf + "\t;;#ASMEND\n\ts_endpgm\n.Lfunc_end0:\n"
+    spaced = bhead + "\tv_cvt_pk_bf16_f32 v93, v1, v2\n\tv_exp_f32_e32 v7, v8\n\tds_read_b128 v[20:23], v101\n\t;;#ASMSTART\n" + mf + "\t;;#ASMEND\n\ts_endpgm\n.Lfunc_end0:\n"
+    early_exit = bhead + "\ts_endpgm\n.LBB0_2:\n\tv_accvgpr_mov_b32 a75, a3\n\t;;#ASMSTART\n" + mf + "\t;;#ASMEND\n\ts_endpgm\n.Lfunc_end0:\n"   # (an early return in front)
+    chain = bhead + "\t;;#ASMSTART\n" + mf + "\t;;#ASMEND\n\t;;#ASMSTART\n" + mf + "\t;;#ASMEND\n\ts_endpgm\n.Lfunc_end0:\n"
     p, n = _asmcheck.check_asm_mfma_operands(hazard)
     assert n == 1 and len(p) == 1 and "v_accvgpr_mov_b32 a75, a3" in p[0]
     assert _asmcheck.check_asm_mfma_operands(padded) == ([], 1)
     assert _asmcheck.check_asm_mfma_operands(spaced) == ([], 1)
     assert _asmcheck.check_asm_mfma_operands(chain) == ([], 2)
+    p, n = _asmcheck.check_asm_mfma_operands(early_exit)
+    assert n == 1 and len(p) == 1   # (the function's first s_endpgm is not its end)
     assert _asmcheck.check_asm_mfma_operands("nothing here\n")[0]
 
 

@@ -4,7 +4,7 @@ import collections, re, sys
 lines = open(sys.argv[1]).read().split("\n")
 kern = sys.argv[2]
 start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and kern in l and ":" in l.split(";")[0])
-end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))   # (not the first s_endpgm: early exits have their own)
 labels = {}
 for i in range(start, end):
     m = re.match(r"^(\.LBB\d+_\d+):", lines[i])
