@@ -12,6 +12,8 @@ E = H * dh
 g = torch.Generator().manual_seed(0)
 sizes = [(256, 1024), (384, 1536), (512, 2048), (640, 2560), (768, 3072), (320, 1200), (448, 1808), (560, 2240)]
 lens = [(h // 16) * (w // 16) for h, w in sizes] * 2
+if os.environ.get("ACAI_RAGGED_SORT"):   # 1: longest first, -1: shortest first (what the batch order is worth)
+    lens = sorted(lens, reverse=os.environ["ACAI_RAGGED_SORT"] == "1")
 tot = sum(lens)
 qkv = (torch.randn(tot, 3 * E, generator=g) * 0.5).to(dev).to(bf)
 dout = torch.randn(tot, E, generator=g).to(dev).to(bf)
@@ -33,4 +35,4 @@ for name, fn in (("fwd", fwd), ("bwd", bwd)):
     res[name] = (time.perf_counter() - t0) / 10 * 1e3
 scores = H * sum(l * l for l in lens)
 print(f"ragged batch of {len(lens)} sequences ({min(lens)}..{max(lens)} tokens, {tot} in all), {H} heads of {dh}: fwd {res['fwd']:.3f} ms  bwd {res['bwd']:.3f} ms "
-      f"({scores / res['bwd'] / 1e9:.2f} T scores/s)  [ACAI_ATTN_BWD_1P={os.environ.get('ACAI_ATTN_BWD_1P', '1')} ACAI_XCD_ORDER={os.environ.get('ACAI_XCD_ORDER', 'auto')}]")
+      f"({scores / res['bwd'] / 1e9:.2f} T scores/s)  [ACAI_ATTN_BWD_1P={os.environ.get('ACAI_ATTN_BWD_1P', '1')} ACAI_XCD_ORDER={os.environ.get('ACAI_XCD_ORDER', 'auto')} ACAI_RAGGED_SORT={os.environ.get('ACAI_RAGGED_SORT', '0')}]")
